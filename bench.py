@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Benchmark of the dense-stereo hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): synthetic rectified
+1920x1080 pairs, D = 256, census -> Hamming cost -> SGM 8-path aggregation -> WTA + uniqueness +
+x16 sub-pixel + LR check, inputs resident in HBM, through the C ABI (mdisp_sgbm_dev).
+One "step" = one batch of `--pairs` stereo pairs per GPU.  With N GPUs every rank processes its own
+batch (pairs are independent: no collective on the data path) -> weak scaling.
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, D = 1920, 1080, 256
+P1, P2 = 8, 32
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
+ALG_BYTES_PER_UNIT = 4.0        # u16 partial-sum volume: written once, read once
+ALG_BYTES_PER_PIXEL = 8.0       # census inputs per sweep + int16 disparity
+
+
+def cpu_baseline(orc, api):
+    """Time the CPU oracle (restatement of the reference path, OpenMP over the host cores) on a
+    bounded sample of the same workload: the top quarter of one frame."""
+    rows = H // 4
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+    L, R = np.ascontiguousarray(L[:rows]), np.ascontiguousarray(R[:rows])
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    t0 = time.perf_counter()
+    orc.sgm(L, R, 0, D, P1, P2, 10, 1, 8, 1)
+    dt = time.perf_counter() - t0
+    return {"value": rows * W * D / dt / 1e6, "unit": "Mdisp/s", "cores": threads, "kind": "port",
+            "sample": f"{W}x{rows} (top quarter of one frame), D={D}, SGM 8-path + LR + subpixel, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=4, help="stereo pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cameracalibration_amd import _lib, api
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = _lib.Context(device=local_rank, stream=stream)
+    params = api.sgbm_params(0, D, P1, P2, 10, 1, 8, 1)
+
+    # synthetic inputs, resident in HBM before the timed region
+    lefts, rights = [], []
+    for i in range(args.pairs):
+        L, R, _ = api.synth_pair(0x5EED0001 + 2 * (rank * args.pairs + i), H, W, D)
+        lefts.append(torch.from_numpy(L).cuda())
+        rights.append(torch.from_numpy(R).cuda())
+    disp = torch.empty((args.pairs, H, W), dtype=torch.int16, device="cuda")
+    ws_bytes = lib.mdisp_sgbm_workspace_bytes(H, W, C.byref(params))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+
+    def step():
+        for i in range(args.pairs):
+            _lib.check(lib.mdisp_sgbm_dev(ctx.handle, lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W,
+                                          C.byref(params), disp[i].data_ptr(), ws.data_ptr(), ws_bytes))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-pair device time of the hot path, HIP events on the stream the kernels run on
+    _lib.check(lib.mdisp_enable_timing(ctx.handle, 1))
+    pair_ms = []
+    for i in range(max(3, min(10, args.steps))):
+        j = i % args.pairs
+        _lib.check(lib.mdisp_sgbm_dev(ctx.handle, lefts[j].data_ptr(), rights[j].data_ptr(), H, W, W,
+                                      C.byref(params), disp[j].data_ptr(), ws.data_ptr(), ws_bytes))
+        ms = C.c_float()
+        _lib.check(lib.mdisp_last_kernel_ms(ctx.handle, 0, C.byref(ms)))
+        pair_ms.append(ms.value)
+    _lib.check(lib.mdisp_enable_timing(ctx.handle, 0))
+    torch.cuda.synchronize()
+    pair_s = float(np.mean(pair_ms)) / 1e3
+
+    units_per_pair = W * H * D
+    total_units = units_per_pair * args.pairs * args.steps * world
+    alg_bytes = ALG_BYTES_PER_UNIT * units_per_pair + ALG_BYTES_PER_PIXEL * W * H
+    achieved = alg_bytes / pair_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "Mdisp/s (WxHxD per sec) at 1920x1080, D=256",
+            "value": total_units / elapsed / 1e6,
+            "unit": "Mdisp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16",
+            "data": "synthetic",
+            "config": {"workload": "1920x1080 D=256 census-Hamming cost + SGM 8-path + WTA/uniqueness + x16 subpixel + LR check",
+                       "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "all launches of one pair (census, 8 path scans, WTA)",
+                         "ms_per_pair": pair_s * 1e3, "algorithmic_bytes_per_pair": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc
+            orc.build()
+            out["cpu_baseline"] = cpu_baseline(orc, api)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

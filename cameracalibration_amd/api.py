@@ -1,0 +1,264 @@
+"""Host-side mirror of the reference's function-level stereo API, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow cameraCalibration/disp_method/methods_disp.h,
+gifs.h, steerFilter.h and methods/methods.h; a numpy array plays the role of cv::Mat.  On bad
+parameters the reference prints a message and returns an empty Mat -- here the same message is
+printed and None is returned.  All compute happens in libmdisp.so on the GPU."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import MdispError, check, image, load, mdisp_param, mdisp_sgbm_params
+
+# CENSUS_ALGORITHM, methods_disp.h:18-27
+BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS, \
+    STATISTIC_MULTISCALE_CENSUS, CENSUS_2017 = range(7)
+# aggregation of the Hamming slices in censusStereo
+AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
+# GIF_TYPE, gifs.h:4-13
+GIF, WGIF, EGIF, SKWGIF = range(4)
+COST_VOLUME, COST_CENSUS, COST_ABSDIFF = range(3)
+# StereoMatchingAlgorithms, methods/parametersStereo.h (only the entry built here)
+SGBM = 1
+
+
+@dataclass
+class StereoMatchParam:
+    """methods_disp.h:5-16.  maxDisparity is inclusive."""
+    imgLeft: Optional[np.ndarray] = None
+    imgRight: Optional[np.ndarray] = None
+    imgLeft_C: Optional[np.ndarray] = None
+    imgRight_C: Optional[np.ndarray] = None
+    winSize: int = 7
+    minDisparity: int = 0
+    maxDisparity: int = 30
+    isDispLeft: bool = True
+
+    def pod(self):
+        return mdisp_param(self.winSize, self.minDisparity, self.maxDisparity, 1 if self.isDispLeft else 0)
+
+
+_BAD = "bad function parameters, please check image and window size."
+
+
+def _ctx(ctx):
+    return (ctx or _lib.default_context()).handle
+
+
+def _u8(a):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError("expected an 8-bit image")
+    return np.ascontiguousarray(a)
+
+
+def _pair_call(fn, param, out_dtype, ctx, *extra):
+    if param.imgLeft is None or param.imgRight is None:
+        print("empty image error")
+        print(_BAD)
+        return None
+    L, R = _u8(param.imgLeft), _u8(param.imgRight)
+    out = np.empty(L.shape[:2], dtype=out_dtype)
+    p = param.pod()
+    rc = fn(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(p), *extra, C.byref(image(out)))
+    if rc == _lib.E_BADARG:
+        print(_BAD)
+        return None
+    check(rc)
+    return out
+
+
+def computeSAD_inteOpti(param, ctx=None):
+    """methods_disp.h:43 -> CV_8U disparity."""
+    return _pair_call(load().mdisp_sad_inte, param, np.uint8, ctx)
+
+
+def computeSAD_BFOpti(param, ctx=None):
+    """methods_disp.h:44 -> CV_8U disparity."""
+    return _pair_call(load().mdisp_sad_box, param, np.uint8, ctx)
+
+
+def censusStereo(param, method=BASIC_CENSUS, agg=AGG_GUIDED, ctx=None):
+    """methods_disp.h:62 -> CV_64F disparity.  `agg` selects the slice aggregation; the reference
+    hard-codes the guided filter (AGG_GUIDED)."""
+    lib = load()
+
+    def fn(h, l, r, p, o):
+        return lib.mdisp_census_stereo(h, l, r, p, method, agg, o)
+    return _pair_call(fn, param, np.float64, ctx)
+
+
+def _census(src, method, arg, ctx):
+    src = _u8(src)
+    dst = np.empty(src.shape[:2], dtype=np.uint8)
+    check(load().mdisp_census_transform(_ctx(ctx), C.byref(image(src)), method, arg, C.byref(image(dst))))
+    return dst
+
+
+def countCensusImg(src, ctx=None):
+    return _census(src, BASIC_CENSUS, 0, ctx)
+
+
+def countCensusImg_circle(src, radius, samplePtNum=8, ctx=None):
+    if samplePtNum != 8:
+        raise ValueError("only 8 sample points are supported")
+    return _census(src, CIRCLE_CENSUS, radius, ctx)
+
+
+def countCensusImg_rotationInv(src, ctx=None):
+    return _census(src, ROTATION_INVARIANT_CENSUS, 0, ctx)
+
+
+def countCensusImg_uniform(src, ctx=None):
+    return _census(src, UNIFORM_CENSUS, 0, ctx)
+
+
+def countCensusImg_multiScale(src, scale, ctx=None):
+    return _census(src, MULTISCALE_CENSUS, scale, ctx)
+
+
+def countHummingDist(src1, src2, ctx=None):
+    a, b = _u8(src1), _u8(src2)
+    dst = np.empty(a.shape, dtype=np.int32)
+    check(load().mdisp_hamming_dist(_ctx(ctx), C.byref(image(a)), C.byref(image(b)), C.byref(image(dst))))
+    return dst
+
+
+def _guided(guide, P, r, eps, gif_type, steerW, r2, namuda, want_beta, ctx):
+    guide = _u8(guide)
+    P = np.ascontiguousarray(P)
+    out = np.empty(guide.shape, dtype=np.float32)
+    beta = np.empty(guide.shape, dtype=np.float32) if want_beta else None
+    sw = None
+    if steerW is not None:
+        sw = np.ascontiguousarray(steerW, dtype=np.float64)
+    check(load().mdisp_guided_filter(_ctx(ctx), C.byref(image(guide)), C.byref(image(P)), r, eps, gif_type,
+                                     C.byref(image(sw)) if sw is not None else None, r2, namuda,
+                                     C.byref(image(out)), C.byref(image(beta)) if want_beta else None))
+    return (out, beta) if want_beta else out
+
+
+def getGuidedFilter(guidedImg, inputP, r, eps, ctx=None):
+    """gifs.h:17"""
+    return _guided(guidedImg, inputP, r, eps, GIF, None, 0, 0.0, False, ctx)
+
+
+def getGuidedFilter_wgif(guidedImg, inputP, r, eps, ctx=None):
+    return _guided(guidedImg, inputP, r, eps, WGIF, None, 0, 0.0, False, ctx)
+
+
+def getGuidedFilter_egif(guidedImg, inputP, r, eps, ctx=None):
+    """gifs.h:21 -> (filtered, beta)"""
+    return _guided(guidedImg, inputP, r, eps, EGIF, None, 0, 0.0, True, ctx)
+
+
+def getGuidedFilter_skwgif2(guidedImg, inputP, steerFilterW, r, r2, eps, namuda, h=0.5, ctx=None):
+    """gifs.h:33 (`h` is accepted and, as in the reference, unused)."""
+    return _guided(guidedImg, inputP, r, eps, SKWGIF, steerFilterW, r2, namuda, False, ctx)
+
+
+def steerFilter(src, ctx=None):
+    """steerFilter.h:39 -> CV_64F orientation-strength map."""
+    src = _u8(src)
+    dst = np.empty(src.shape, dtype=np.float64)
+    check(load().mdisp_steer_filter(_ctx(ctx), C.byref(image(src)), C.byref(image(dst))))
+    return dst
+
+
+def asw_gifs(param, eps, gifType=GIF, r2=5, namda=0.1, h=0.5, cost_source=COST_CENSUS, costs=None, ctx=None):
+    """methods_disp.h:66 -> CV_32F disparity.  The reference feeds dense-SIFT costs
+    (computeDisp_Feature); pass them as `costs` (numDisp x H x W float32) with
+    cost_source=COST_VOLUME, or let the GPU build census / absdiff slices."""
+    lib = load()
+    cptr = None
+    if cost_source == COST_VOLUME:
+        costs = np.ascontiguousarray(costs, dtype=np.float32)
+        cptr = costs.ctypes.data
+
+    def fn(hd, l, r, p, o):
+        return lib.mdisp_asw_gifs(hd, l, r, p, eps, gifType, r2, namda, h, cost_source, cptr, o)
+    return _pair_call(fn, param, np.float32, ctx)
+
+
+def sgbm_params(minDisparity=0, numDisparities=64, P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=0, paths=8,
+                subpixel=1, costWin=1, censusMethod=BASIC_CENSUS):
+    return mdisp_sgbm_params(minDisparity, numDisparities, P1, P2, uniquenessRatio, disp12MaxDiff, paths, subpixel,
+                             costWin, censusMethod)
+
+
+def sgbm_compute(srcLeft, srcRight, params, ctx=None):
+    """cv::StereoSGBM::compute replacement -> CV_16S disparity x16."""
+    L, R = _u8(srcLeft), _u8(srcRight)
+    out = np.empty(L.shape[:2], dtype=np.int16)
+    check(load().mdisp_sgbm(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(params), C.byref(image(out))))
+    return out
+
+
+def getDisparity_SGBM(srcLeft, srcRight, ctx=None):
+    """methods/methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7) then `disp / 16`
+    (a CV_16S MatExpr divide: round half to even)."""
+    if srcLeft is None or srcRight is None:
+        print(" --(!) Error reading images ")
+        return None
+    d16 = sgbm_compute(srcLeft, srcRight, sgbm_params(0, 48, paths=5), ctx)
+    return np.rint(d16.astype(np.float64) / 16.0).astype(np.int16)
+
+
+def stereoMatching(srcLeft, srcRight, algorithmType=SGBM, ctx=None):
+    """methods/methods.cpp:1776-1813 (SGBM entry)."""
+    if algorithmType != SGBM:
+        raise NotImplementedError("only the SGBM entry of stereoMatching is on the hot path")
+    return getDisparity_SGBM(srcLeft, srcRight, ctx)
+
+
+def lr_check(dispL, dispR, thresh=1.0, ctx=None):
+    """PatchMatch::postProcess validity masks, methods/patchmatch.cpp:817-828."""
+    a = np.ascontiguousarray(dispL, dtype=np.float32)
+    b = np.ascontiguousarray(dispR, dtype=np.float32)
+    vl = np.empty(a.shape, dtype=np.uint8)
+    vr = np.empty(a.shape, dtype=np.uint8)
+    check(load().mdisp_lr_check(_ctx(ctx), C.byref(image(a)), C.byref(image(b)), thresh, C.byref(image(vl)),
+                                C.byref(image(vr))))
+    return vl, vr
+
+
+def initUndistortRectifyMap(K, dist, R, P, size):
+    """cv::initUndistortRectifyMap(..., CV_16SC2): returns (map1 int16 HxWx2, map2 uint16 HxW)."""
+    W, H = size
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    if P.size == 9:
+        P = np.hstack([P.reshape(3, 3), np.zeros((3, 1))])
+    P = np.ascontiguousarray(P.reshape(12))
+    dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+    m1 = np.empty((H, W, 2), dtype=np.int16)
+    m2 = np.empty((H, W), dtype=np.uint16)
+    dp = C.POINTER(C.c_double)
+    check(load().mdisp_build_rectify_maps(K.ctypes.data_as(dp), dist.ctypes.data_as(dp), dist.size,
+                                          R.ctypes.data_as(dp), P.ctypes.data_as(dp), W, H, m1.ctypes.data,
+                                          m2.ctypes.data))
+    return m1, m2
+
+
+def remap(src, map1, map2, ctx=None):
+    """cv::remap(src, dst, map1, map2, INTER_LINEAR), constant-0 border."""
+    src = _u8(src)
+    m1 = np.ascontiguousarray(map1, dtype=np.int16)
+    m2 = np.ascontiguousarray(map2, dtype=np.uint16)
+    shape = m2.shape + ((src.shape[2],) if src.ndim == 3 else ())
+    dst = np.empty(shape, dtype=np.uint8)
+    check(load().mdisp_remap(_ctx(ctx), C.byref(image(src)), m1.ctypes.data, m2.ctypes.data, C.byref(image(dst))))
+    return dst
+
+
+def synth_pair(seed, rows, cols, numDisp):
+    """Synthetic rectified pair (left, right, ground-truth disparity)."""
+    left = np.empty((rows, cols), dtype=np.uint8)
+    right = np.empty((rows, cols), dtype=np.uint8)
+    gt = np.empty((rows, cols), dtype=np.uint16)
+    check(load().mdisp_synth_pair(seed, rows, cols, numDisp, left.ctypes.data, right.ctypes.data, gt.ctypes.data))
+    return left, right, gt

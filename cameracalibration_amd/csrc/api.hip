@@ -1,0 +1,461 @@
+// C ABI of libmdisp.so: contexts, host-buffer entry points (upload -> kernels -> download) and
+// device-resident entry points.  See include/mdisp.h for the contract of every function.
+#include "common.h"
+#include <stdarg.h>
+#include <stdlib.h>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void mdisp_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mdisp_last_error(void) { return g_err; }
+extern "C" int mdisp_version(void) { return 100; }
+
+extern "C" int mdisp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
+{
+    MD_REQUIRE(out, MDISP_E_BADARG, "null context pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        mdisp_set_error("no HIP device available; libmdisp has no CPU fallback");
+        return MDISP_E_NODEVICE;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    MD_REQUIRE(device < n, MDISP_E_BADARG, "device %d out of range (%d present)", device, n);
+    if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
+    mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
+    MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false;
+    for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c; mdisp_set_error("hipStreamCreate failed"); return MDISP_E_HIP;
+        }
+        c->own_stream = true;
+    }
+    for (int i = 0; i < 6; i++)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { mdisp_set_error("hipEventCreate failed"); delete c; return MDISP_E_HIP; }
+    *out = c;
+    return MDISP_OK;
+}
+
+extern "C" void mdisp_destroy(mdisp_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mdisp_synchronize(mdisp_ctx* c)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+void* mdisp_ws(mdisp_ctx* c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return c->ws;
+    // the stream may still be reading the old block
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { mdisp_set_error("stream sync failed"); return nullptr; }
+    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    size_t want = md_align(bytes + bytes / 8, 1 << 20);
+    if (hipMalloc(&c->ws, want) != hipSuccess) {
+        mdisp_set_error("hipMalloc(%zu) for the workspace failed", want);
+        c->ws = nullptr;
+        return nullptr;
+    }
+    c->ws_bytes = want;
+    return c->ws;
+}
+
+extern "C" int mdisp_enable_timing(mdisp_ctx* c, int on)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    c->timing = on != 0;
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_last_kernel_ms(mdisp_ctx* c, int which, float* ms)
+{
+    MD_REQUIRE(c && ms && which >= 0 && which < 3, MDISP_E_BADARG, "bad arguments");
+    MD_REQUIRE(c->ev_valid[which], MDISP_E_BADARG, "no timed call recorded (enable timing first)");
+    MD_HIP(hipEventSynchronize(c->ev[2 * which + 1]));
+    MD_HIP(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+
+static size_t depth_bytes(int depth)
+{
+    switch (depth) {
+    case MDISP_8U: case MDISP_8S: return 1;
+    case MDISP_16U: case MDISP_16S: return 2;
+    case MDISP_32S: case MDISP_32F: return 4;
+    case MDISP_64F: return 8;
+    default: return 0;
+    }
+}
+
+static int check_image(const mdisp_image* im, const char* what)
+{
+    MD_REQUIRE(im && im->data, MDISP_E_BADARG, "%s: empty image", what);
+    MD_REQUIRE(im->rows > 0 && im->cols > 0 && im->channels > 0 && depth_bytes(im->depth) > 0, MDISP_E_BADARG,
+               "%s: bad image header", what);
+    MD_REQUIRE(im->step_bytes >= (size_t)im->cols * im->channels * depth_bytes(im->depth), MDISP_E_BADARG,
+               "%s: step smaller than a row", what);
+    return MDISP_OK;
+}
+
+static int check_out(const mdisp_image* im, int rows, int cols, int depth, int channels, const char* what)
+{
+    int rc = check_image(im, what);
+    if (rc) return rc;
+    MD_REQUIRE(im->rows == rows && im->cols == cols && im->depth == depth && im->channels == channels, MDISP_E_BADARG,
+               "%s: expected %dx%d depth %d channels %d, got %dx%d depth %d channels %d", what, cols, rows, depth,
+               channels, im->cols, im->rows, im->depth, im->channels);
+    return MDISP_OK;
+}
+
+// bump allocator over the context workspace
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off = md_align(off + bytes, 256); return o; }
+};
+
+// Upload an 8-bit image as single-channel gray (checkImg, methods_disp.cpp:130-147: 3-channel
+// input goes through COLOR_BGR2GRAY).  `stage` is device scratch for the interleaved BGR rows.
+static int upload_gray(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch, u8* stage, size_t stage_pitch)
+{
+    MD_REQUIRE(im->depth == MDISP_8U, MDISP_E_UNSUPPORTED, "only CV_8U images are supported (got depth %d)", im->depth);
+    if (im->channels == 1) {
+        MD_HIP(hipMemcpy2DAsync(d, dpitch, im->data, im->step_bytes, im->cols, im->rows, hipMemcpyHostToDevice, c->stream));
+        return MDISP_OK;
+    }
+    MD_REQUIRE(im->channels == 3, MDISP_E_UNSUPPORTED, "only 1- or 3-channel images are supported");
+    MD_HIP(hipMemcpy2DAsync(stage, stage_pitch, im->data, im->step_bytes, (size_t)im->cols * 3, im->rows, hipMemcpyHostToDevice, c->stream));
+    return md_bgr2gray(c->stream, stage, stage_pitch, im->rows, im->cols, d, dpitch);
+}
+
+static int census_arg_for(int method, int winSize, int leftBranch)
+{
+    // per-branch literals of censusStereo: methods_disp.cpp:885,927 vs :1028,1070
+    if (method == MDISP_CIRCLE_CENSUS) return leftBranch ? 5 : winSize;
+    if (method == MDISP_MULTISCALE_CENSUS) return leftBranch ? 16 : winSize;
+    return winSize;
+}
+
+// ---------------------------------------------------------------------------------------------
+// census / Hamming
+
+extern "C" int mdisp_census_transform(mdisp_ctx* c, const mdisp_image* src, int method, int arg, mdisp_image* dst)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(src, "src"))) return rc;
+    if ((rc = check_out(dst, src->rows, src->cols, MDISP_8U, 1, "dst"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = src->rows, W = src->cols;
+    const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
+    Carver cv;
+    size_t o_src = cv.take(pitch * H), o_dst = cv.take(pitch * H), o_scr = cv.take(pitch * H), o_stage = cv.take(p3 * H);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_gray(c, src, base + o_src, pitch, base + o_stage, p3))) return rc;
+    if ((rc = md_census(c->stream, base + o_src, pitch, H, W, method, arg, base + o_dst, pitch, base + o_scr))) return rc;
+    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_dst, pitch, W, H, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_hamming_dist(mdisp_ctx* c, const mdisp_image* a, const mdisp_image* b, mdisp_image* dst)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(a, "src1")) || (rc = check_image(b, "src2"))) return rc;
+    MD_REQUIRE(a->rows == b->rows && a->cols == b->cols && a->depth == MDISP_8U && b->depth == MDISP_8U &&
+               a->channels == 1 && b->channels == 1, MDISP_E_BADARG, "Hamming distance needs two CV_8UC1 images of equal size");
+    if ((rc = check_out(dst, a->rows, a->cols, MDISP_32S, 1, "dst"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = a->rows, W = a->cols;
+    const size_t pitch = md_align(W, 256), p4 = md_align((size_t)W * 4, 256);
+    Carver cv;
+    size_t o_a = cv.take(pitch * H), o_b = cv.take(pitch * H), o_d = cv.take(p4 * H);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_HIP(hipMemcpy2DAsync(base + o_a, pitch, a->data, a->step_bytes, W, H, hipMemcpyHostToDevice, c->stream));
+    MD_HIP(hipMemcpy2DAsync(base + o_b, pitch, b->data, b->step_bytes, W, H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = md_hamming(c->stream, base + o_a, pitch, base + o_b, pitch, H, W, (int32_t*)(base + o_d), p4))) return rc;
+    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_d, p4, (size_t)W * 4, H, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// window-cost stereo (census stereo, SAD box, SAD integral)
+
+static int check_pair(const mdisp_image* L, const mdisp_image* R, const mdisp_param* p)
+{
+    int rc;
+    if ((rc = check_image(L, "imgLeft")) || (rc = check_image(R, "imgRight"))) return rc;
+    MD_REQUIRE(p, MDISP_E_BADARG, "null parameters");
+    // checkPairs + winSize parity, methods_disp.cpp:209-215
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG,
+               "bad function parameters, please check image and window size.");
+    MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0, MDISP_E_BADARG,
+               "bad function parameters, please check image and window size.");
+    MD_REQUIRE(p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity, MDISP_E_BADARG, "bad disparity range");
+    return MDISP_OK;
+}
+
+struct PairBufs {
+    u8 *ref, *other, *pad, *cRef, *cPad, *scr, *stage;
+    size_t pitchW, pitchP, pitch3;
+    void* out; int* I; int* best;
+};
+
+// lay out and upload a pair; `ref` is the view the disparity is computed for
+static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p,
+                      size_t out_bytes, bool need_sat, PairBufs* b)
+{
+    const int H = L->rows, W = L->cols, Wp = W + p->maxDisparity;
+    b->pitchW = md_align(W, 256); b->pitchP = md_align(Wp, 256); b->pitch3 = md_align((size_t)W * 3, 256);
+    Carver cv;
+    size_t o_ref = cv.take(b->pitchW * H), o_oth = cv.take(b->pitchW * H), o_pad = cv.take(b->pitchP * H);
+    size_t o_cr = cv.take(b->pitchP * H), o_cp = cv.take(b->pitchP * H), o_scr = cv.take(b->pitchP * H);
+    size_t o_st = cv.take(b->pitch3 * H), o_out = cv.take(out_bytes);
+    size_t o_I = 0, o_best = 0;
+    if (need_sat) { o_I = cv.take((size_t)(H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 4); }
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    b->ref = base + o_ref; b->other = base + o_oth; b->pad = base + o_pad; b->cRef = base + o_cr; b->cPad = base + o_cp;
+    b->scr = base + o_scr; b->stage = base + o_st; b->out = base + o_out;
+    b->I = (int*)(base + o_I); b->best = (int*)(base + o_best);
+    int rc;
+    const mdisp_image* refIm = p->isDispLeft ? L : R;
+    const mdisp_image* othIm = p->isDispLeft ? R : L;
+    if ((rc = upload_gray(c, refIm, b->ref, b->pitchW, b->stage, b->pitch3))) return rc;
+    if ((rc = upload_gray(c, othIm, b->other, b->pitchW, b->stage, b->pitch3))) return rc;
+    return MDISP_OK;
+}
+
+// Device-side body shared by the host and _dev census-stereo entry points.
+static int census_stereo_body(mdisp_ctx* c, const u8* ref, const u8* other, size_t pitch, int H, int W,
+                              const mdisp_param* p, int method, int agg, u8* pad, size_t pitchP, u8* cRef, size_t pitchC,
+                              u8* cPad, u8* scr, double* dOut)
+{
+    const int maxD = p->maxDisparity, minD = p->minDisparity, Wp = W + maxD;
+    int rc;
+    hipStream_t s = c->stream;
+    MD_REQUIRE(agg == MDISP_AGG_NONE || agg == MDISP_AGG_BOX || agg == MDISP_AGG_SQRBOX, MDISP_E_UNSUPPORTED,
+               "aggregation mode %d is not built yet", agg);
+    // left-disparity branch pads the right image on the left (:862), right-disparity branch pads
+    // the left image on the right (:1005); both BORDER_REFLECT
+    if (p->isDispLeft) rc = md_pad_reflect_lr(s, other, pitch, H, W, maxD, 0, pad, pitchP);
+    else rc = md_pad_reflect_lr(s, other, pitch, H, W, 0, maxD, pad, pitchP);
+    if (rc) return rc;
+    const int arg = census_arg_for(method, p->winSize, p->isDispLeft);
+    if ((rc = md_census(s, ref, pitch, H, W, method, arg, cRef, pitchC, scr))) return rc;
+    if ((rc = md_census(s, pad, pitchP, H, Wp, method, arg, cPad, pitchP, scr))) return rc;
+    const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
+    const int win = agg == MDISP_AGG_NONE ? 1 : p->winSize;
+    const int kind = agg == MDISP_AGG_SQRBOX ? MD_COST_HAMMING_SQR : MD_COST_HAMMING;
+    return md_cost_box_wta(s, cRef, pitchC, cPad, pitchP, H, W, minD, maxD, off0, offStep, win, kind, MD_OUT_F64, dOut, W);
+}
+
+extern "C" int mdisp_census_stereo(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p,
+                                   int census_method, int agg_mode, mdisp_image* out)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_pair(L, R, p))) return rc;
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_64F, 1, "out"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols;
+    PairBufs b;
+    if ((rc = stage_pair(c, L, R, p, (size_t)H * W * 8, false, &b))) return rc;
+    // census rows are read as dwords: the census of `ref` uses the padded-width pitch as well
+    if ((rc = census_stereo_body(c, b.ref, b.other, b.pitchW, H, W, p, census_method, agg_mode, b.pad, b.pitchP, b.cRef,
+                                 b.pitchP, b.cPad, b.scr, (double*)b.out))) return rc;
+    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, (size_t)W * 8, (size_t)W * 8, H, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_census_stereo_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                                       size_t pitch, const mdisp_param* p, int census_method, int agg_mode, double* d_disp)
+{
+    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(rows > 0 && cols > 0 && pitch >= (size_t)cols && pitch % 4 == 0, MDISP_E_BADARG,
+               "bad geometry (pitch must be a multiple of 4 and >= cols)");
+    MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0 && p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity,
+               MDISP_E_BADARG, "bad function parameters, please check image and window size.");
+    MD_HIP(hipSetDevice(c->device));
+    const int Wp = cols + p->maxDisparity;
+    const size_t pitchP = md_align(Wp, 256);
+    Carver cv;
+    size_t o_pad = cv.take(pitchP * rows), o_cr = cv.take(pitchP * rows), o_cp = cv.take(pitchP * rows), o_scr = cv.take(pitchP * rows);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    const u8* ref = p->isDispLeft ? d_left : d_right;
+    const u8* other = p->isDispLeft ? d_right : d_left;
+    return census_stereo_body(c, ref, other, pitch, rows, cols, p, census_method, agg_mode, base + o_pad, pitchP,
+                              base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp);
+}
+
+static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out, bool inte)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_pair(L, R, p))) return rc;
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_8U, 1, "out"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols, maxD = p->maxDisparity, minD = p->minDisparity;
+    PairBufs b;
+    const size_t opitch = md_align(W, 256);
+    if ((rc = stage_pair(c, L, R, p, opitch * H, inte, &b))) return rc;
+    hipStream_t s = c->stream;
+    if (p->isDispLeft) rc = md_pad_reflect_lr(s, b.other, b.pitchW, H, W, maxD, 0, b.pad, b.pitchP);
+    else rc = md_pad_reflect_lr(s, b.other, b.pitchW, H, W, 0, maxD, b.pad, b.pitchP);
+    if (rc) return rc;
+    const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
+    if (inte) rc = md_sad_inte(s, b.ref, b.pitchW, b.pad, b.pitchP, H, W, minD, maxD, off0, offStep, p->winSize,
+                               (u8*)b.out, opitch, b.I, b.best);
+    else rc = md_cost_box_wta(s, b.ref, b.pitchW, b.pad, b.pitchP, H, W, minD, maxD, off0, offStep, p->winSize,
+                              MD_COST_ABSDIFF_SQR, MD_OUT_U8, b.out, opitch);
+    if (rc) return rc;
+    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, opitch, W, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_sad_inte(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out)
+{ return sad_common(c, L, R, p, out, true); }
+
+extern "C" int mdisp_sad_box(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out)
+{ return sad_common(c, L, R, p, out, false); }
+
+// ---------------------------------------------------------------------------------------------
+// SGM
+
+extern "C" size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p)
+{
+    md_sgm_plan pl;
+    if (md_sgm_plan_make(rows, cols, p, &pl)) return 0;
+    return pl.total;
+}
+
+extern "C" int mdisp_sgbm_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                              const mdisp_sgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes)
+{
+    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(pitch >= (size_t)cols, MDISP_E_BADARG, "pitch smaller than a row");
+    md_sgm_plan pl;
+    int rc;
+    if ((rc = md_sgm_plan_make(rows, cols, p, &pl))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    void* ws = d_workspace;
+    if (ws) MD_REQUIRE(workspace_bytes >= pl.total, MDISP_E_BADARG, "workspace too small: %zu < %zu", workspace_bytes, pl.total);
+    else { ws = mdisp_ws(c, pl.total); if (!ws) return MDISP_E_NOMEM; }
+    if (c->timing) MD_HIP(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = md_sgm_run(c, pl, d_left, d_right, pitch, d_disp, ws))) return rc;
+    if (c->timing) { MD_HIP(hipEventRecord(c->ev[1], c->stream)); c->ev_valid[0] = true; }
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_16S, 1, "out"))) return rc;
+    md_sgm_plan pl;
+    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, &pl))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols;
+    const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
+    Carver cv;
+    size_t o_ws = cv.take(pl.total), o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_st = cv.take(p3 * H), o_d = cv.take((size_t)H * W * 2);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
+    if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
+    if ((rc = md_sgm_run(c, pl, base + o_l, base + o_r, pitch, (int16_t*)(base + o_d), base + o_ws))) return rc;
+    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LR check, remap, rectification maps
+
+extern "C" int mdisp_lr_check(mdisp_ctx* c, const mdisp_image* dL, const mdisp_image* dR, float thresh,
+                              mdisp_image* validL, mdisp_image* validR)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(dL, "dispL")) || (rc = check_image(dR, "dispR"))) return rc;
+    MD_REQUIRE(dL->depth == MDISP_32F && dR->depth == MDISP_32F && dL->channels == 1 && dR->channels == 1 &&
+               dL->rows == dR->rows && dL->cols == dR->cols, MDISP_E_BADARG, "LR check needs two CV_32FC1 maps of equal size");
+    if ((rc = check_out(validL, dL->rows, dL->cols, MDISP_8U, 1, "validL")) || (rc = check_out(validR, dL->rows, dL->cols, MDISP_8U, 1, "validR"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = dL->rows, W = dL->cols;
+    Carver cv;
+    size_t o_l = cv.take((size_t)H * W * 4), o_r = cv.take((size_t)H * W * 4), o_vl = cv.take((size_t)H * W), o_vr = cv.take((size_t)H * W);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    hipStream_t s = c->stream;
+    MD_HIP(hipMemcpy2DAsync(base + o_l, (size_t)W * 4, dL->data, dL->step_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
+    MD_HIP(hipMemcpy2DAsync(base + o_r, (size_t)W * 4, dR->data, dR->step_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
+    if ((rc = md_lr_check(s, (float*)(base + o_l), (float*)(base + o_r), H, W, thresh, base + o_vl, base + o_vr))) return rc;
+    MD_HIP(hipMemcpy2DAsync(validL->data, validL->step_bytes, base + o_vl, W, W, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipMemcpy2DAsync(validR->data, validR->step_bytes, base + o_vr, W, W, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_remap(mdisp_ctx* c, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst)
+{
+    MD_REQUIRE(c && map1 && map2, MDISP_E_BADARG, "null argument");
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    MD_REQUIRE(src->depth == MDISP_8U && dst->depth == MDISP_8U && src->channels == dst->channels &&
+               (src->channels == 1 || src->channels == 3), MDISP_E_BADARG, "remap needs CV_8UC1 or CV_8UC3 images");
+    MD_HIP(hipSetDevice(c->device));
+    const int sH = src->rows, sW = src->cols, dH = dst->rows, dW = dst->cols, cn = src->channels;
+    const size_t sp = md_align((size_t)sW * cn, 256), dp = md_align((size_t)dW * cn, 256);
+    Carver cv;
+    size_t o_s = cv.take(sp * sH), o_d = cv.take(dp * dH), o_m1 = cv.take((size_t)dH * dW * 4), o_m2 = cv.take((size_t)dH * dW * 2);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    hipStream_t s = c->stream;
+    MD_HIP(hipMemcpy2DAsync(base + o_s, sp, src->data, src->step_bytes, (size_t)sW * cn, sH, hipMemcpyHostToDevice, s));
+    MD_HIP(hipMemcpyAsync(base + o_m1, map1, (size_t)dH * dW * 4, hipMemcpyHostToDevice, s));
+    MD_HIP(hipMemcpyAsync(base + o_m2, map2, (size_t)dH * dW * 2, hipMemcpyHostToDevice, s));
+    if ((rc = md_remap(s, base + o_s, sp, sH, sW, cn, (const int16_t*)(base + o_m1), (const u16*)(base + o_m2), dH, dW, base + o_d, dp))) return rc;
+    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_d, dp, (size_t)dW * cn, dH, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}

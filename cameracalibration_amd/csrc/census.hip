@@ -1,0 +1,288 @@
+// Census family, Hamming distance, reflect padding and BGR->gray for gfx950.
+//
+// Replaces countCensusImg / _rotationInv / _uniform / _multiScale / _circle and countHummingDist
+// of cameraCalibration/disp_method/methods_disp.cpp:415-714, 808-838, plus the
+// copyMakeBorder(BORDER_REFLECT) calls at :224,268,862,1005 and checkImg's cvtColor (:138-141).
+#include "common.h"
+#include <math.h>
+
+// cv::borderInterpolate(BORDER_REFLECT): fedcba|abcdef|fedcba
+__device__ __forceinline__ int reflect_idx(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p - 1 : 2 * n - p - 1;
+    return p;
+}
+
+// 16 bytes per lane along x; rows over blockIdx.y
+__global__ __launch_bounds__(256) void pad_reflect_lr_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
+                                                              int left, int Wp, u8* __restrict__ dst, size_t dp)
+{
+    int y = blockIdx.y;
+    int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= Wp) return;
+    const u8* srow = src + (size_t)y * sp;
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x4 + i;
+        u32 b = x < Wp ? srow[reflect_idx(x - left, W)] : 0;
+        v |= b << (8 * i);
+    }
+    // dst pitch is a multiple of 4 and covers the rounded-up width
+    *reinterpret_cast<u32*>(dst + (size_t)y * dp + x4) = v;
+}
+
+struct CensusLut { u8 t[256]; };
+
+// 3x3 census with the reference's bit order (7=TL 6=T 5=TR 4=R 3=BR 2=B 1=BL 0=L, nbr >= centre),
+// 1-px frame left 0, optional 256-entry LUT applied to the code (rotation-invariant / uniform).
+// Tile: 256 x 16 pixels per 256-thread workgroup, staged in LDS with a 1-px halo; each thread
+// produces 4 horizontally adjacent codes per row and stores them as one dword.
+#define CT_W 256
+#define CT_H 16
+#define CT_LW (CT_W + 8)   // 4 bytes of halo on each side keeps rows dword-aligned
+template <bool USE_LUT>
+__global__ __launch_bounds__(256) void census3x3_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
+                                                        u8* __restrict__ dst, size_t dp, CensusLut lut)
+{
+    __shared__ u32 tile[(CT_H + 2) * (CT_LW / 4)];
+    __shared__ u8 slut[256];
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int t = threadIdx.x;
+    if (USE_LUT) slut[t] = lut.t[t];
+    constexpr int DW = CT_LW / 4;   // dwords per LDS row
+    for (int i = t; i < (CT_H + 2) * DW; i += 256) {
+        int r = i / DW, c = i % DW;
+        int y = y0 - 1 + r, x = x0 - 4 + 4 * c;
+        u32 v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W)   // rows are padded to a multiple of 4 bytes
+            v = *reinterpret_cast<const u32*>(src + (size_t)y * sp + x);
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int tx = t & 63, ty = t >> 6;
+    const u8* tb = reinterpret_cast<const u8*>(tile);
+#pragma unroll
+    for (int rr = 0; rr < CT_H / 4; rr++) {
+        int ly = ty + 4 * rr;          // tile row
+        int y = y0 + ly;
+        if (y >= H) break;
+        int xg = x0 + 4 * tx;
+        if (xg >= W) continue;
+        const u8* r0 = tb + (ly + 0) * CT_LW + 4 + 4 * tx;   // row y-1, column xg
+        const u8* r1 = r0 + CT_LW;
+        const u8* r2 = r1 + CT_LW;
+        u32 out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int x = xg + i;
+            u32 code = 0;
+            if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+                u32 c = r1[i];
+                code |= (u32)(r0[i - 1] >= c) << 7;
+                code |= (u32)(r0[i] >= c) << 6;
+                code |= (u32)(r0[i + 1] >= c) << 5;
+                code |= (u32)(r1[i + 1] >= c) << 4;
+                code |= (u32)(r2[i + 1] >= c) << 3;
+                code |= (u32)(r2[i] >= c) << 2;
+                code |= (u32)(r2[i - 1] >= c) << 1;
+                code |= (u32)(r1[i - 1] >= c) << 0;
+                if (USE_LUT) code = slut[code];
+            }
+            out |= code << (8 * i);
+        }
+        *reinterpret_cast<u32*>(dst + (size_t)y * dp + xg) = out;
+    }
+}
+
+// cell-mean image of countCensusImg_multiScale (methods_disp.cpp:649-667): mean over a
+// (2*offset+1)^2 block divided (integer) by cellSize^2, zero within `offset` of the border.
+__global__ __launch_bounds__(256) void cell_mean_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
+                                                        int cellSize, u8* __restrict__ dst, size_t dp)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    int offset = cellSize / 2;
+    u32 v = 0;
+    if (cellSize > 0 && y >= offset && y < H - offset && x >= offset && x < W - offset) {
+        int s = 0;
+        for (int n = -offset; n <= offset; n++)
+            for (int m = -offset; m <= offset; m++) s += src[(size_t)(y + n) * sp + x + m];
+        v = (u32)(s / (cellSize * cellSize)) & 0xFF;
+    }
+    dst[(size_t)y * dp + x] = (u8)v;
+}
+
+struct CircleTaps { int fx[8], fy[8], cx[8], cy[8]; float w1[8], w2[8], w3[8], w4[8]; };
+
+// countCensusImg_circle (methods_disp.cpp:456-500) restated deterministically: every output pixel
+// sums its own sample bits (the reference accumulates them from racing OpenMP threads) and, as in
+// the reference, the code of pixel (i,j) lands at (i-radius, j-radius).  The float expression is
+// evaluated without fused multiply-add, left to right, as the reference's compiler would.
+__global__ __launch_bounds__(256) void census_circle_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
+                                                            int radius, int npts, CircleTaps taps,
+                                                            u8* __restrict__ dst, size_t dp)
+{
+    int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;   // output coordinates
+    if (ox >= W) return;
+    int i = oy + radius, j = ox + radius;
+    u32 code = 0;
+    if (i < H - radius && j < W - radius) {
+        float c = (float)src[(size_t)i * sp + j];
+        for (int n = 0; n < npts; n++) {
+            float a = (float)src[(size_t)(i + taps.fy[n]) * sp + j + taps.fx[n]];
+            float b = (float)src[(size_t)(i + taps.fy[n]) * sp + j + taps.cx[n]];
+            float cc = (float)src[(size_t)(i + taps.cy[n]) * sp + j + taps.fx[n]];
+            float d = (float)src[(size_t)(i + taps.cy[n]) * sp + j + taps.cx[n]];
+            float tv = __fmul_rn(taps.w1[n], a);
+            tv = __fadd_rn(tv, __fmul_rn(taps.w2[n], b));
+            tv = __fadd_rn(tv, __fmul_rn(taps.w3[n], cc));
+            tv = __fadd_rn(tv, __fmul_rn(taps.w4[n], d));
+            u32 bit = (tv > c) || (fabsf(__fsub_rn(tv, c)) < 1.1920928955078125e-07f);
+            code = (code + (bit << n)) & 0xFF;
+        }
+    }
+    dst[(size_t)oy * dp + ox] = (u8)code;
+}
+
+__global__ __launch_bounds__(256) void hamming_kernel(const u8* __restrict__ a, size_t ap, const u8* __restrict__ b,
+                                                      size_t bp, int H, int W, int32_t* __restrict__ dst, size_t dp)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    dst[(size_t)y * (dp / 4) + x] = __popc((u32)(a[(size_t)y * ap + x] ^ b[(size_t)y * bp + x]));
+}
+
+// OpenCV 8-bit BGR2GRAY: (B*1868 + G*9617 + R*4899 + 2^13) >> 14
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const u8* __restrict__ bgr, size_t sp, int H, int W,
+                                                       u8* __restrict__ gray, size_t dp)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const u8* p = bgr + (size_t)y * sp + 3 * x;
+    gray[(size_t)y * dp + x] = (u8)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+}
+
+// ---------------------------------------------------------------------------------------------
+
+int md_pad_reflect_lr(hipStream_t s, const u8* src, size_t spitch, int H, int W, int left, int right, u8* dst, size_t dpitch)
+{
+    int Wp = W + left + right;
+    dim3 grid((Wp + 1023) / 1024, H);
+    pad_reflect_lr_kernel<<<grid, 256, 0, s>>>(src, spitch, H, W, left, Wp, dst, dpitch);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// RITable of countCensusImg_rotationInv (methods_disp.cpp:519-533): the loop never rotates, the
+// table is min(i, i>>1) = i>>1.
+static void ri_table(u8* t)
+{
+    for (int i = 0; i < 256; i++) {
+        int val = i;
+        for (int j = 0; j < 7; j++) { int temp = i >> 1; if (val > temp) val = temp; }
+        t[i] = (u8)val;
+    }
+}
+
+// hopCount (methods_disp.cpp:562-580): transitions of the circular pattern 0,b6,b5,...,b0.
+static int hop_count(unsigned i)
+{
+    int a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 7; k >= 1; k--) { a[k] = i & 1; i >>= 1; }
+    int cnt = 0;
+    for (int j = 0; j < 8; j++) cnt += a[j] != a[(j + 1) & 7];
+    return cnt;
+}
+
+// UPTable of countCensusImg_uniform (methods_disp.cpp:599-609)
+static void uniform_table(u8* t)
+{
+    memset(t, 0, 256);
+    u8 temp = 1;
+    for (int i = 0; i < 256; i++)
+        if (hop_count(i) <= 2) t[i] = temp++;
+}
+
+static int launch_census3x3(hipStream_t s, const u8* src, size_t sp, int H, int W, u8* dst, size_t dp, const u8* lut)
+{
+    dim3 grid((W + CT_W - 1) / CT_W, (H + CT_H - 1) / CT_H);
+    CensusLut l;
+    if (lut) {
+        memcpy(l.t, lut, 256);
+        census3x3_kernel<true><<<grid, 256, 0, s>>>(src, sp, H, W, dst, dp, l);
+    } else {
+        memset(l.t, 0, 256);
+        census3x3_kernel<false><<<grid, 256, 0, s>>>(src, sp, H, W, dst, dp, l);
+    }
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// src and dst rows must be padded to a multiple of 4 bytes (pitch % 4 == 0, pitch >= roundup4(W)).
+int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int method, int arg, u8* dst, size_t dpitch,
+              u8* scratch)
+{
+    u8 lut[256];
+    switch (method) {
+    case MDISP_BASIC_CENSUS:
+        return launch_census3x3(s, src, spitch, H, W, dst, dpitch, nullptr);
+    case MDISP_ROTATION_INVARIANT_CENSUS:
+        ri_table(lut);
+        return launch_census3x3(s, src, spitch, H, W, dst, dpitch, lut);
+    case MDISP_UNIFORM_CENSUS:
+        uniform_table(lut);
+        return launch_census3x3(s, src, spitch, H, W, dst, dpitch, lut);
+    case MDISP_MULTISCALE_CENSUS: {
+        MD_REQUIRE(scratch, MDISP_E_BADARG, "multi-scale census needs a scratch image");
+        dim3 grid((W + 255) / 256, H);
+        cell_mean_kernel<<<grid, 256, 0, s>>>(src, spitch, H, W, arg / 3, scratch, dpitch);
+        MD_HIP(hipGetLastError());
+        return launch_census3x3(s, scratch, dpitch, H, W, dst, dpitch, nullptr);
+    }
+    case MDISP_CIRCLE_CENSUS: {
+        int radius = arg, npts = 8;
+        MD_REQUIRE(radius >= 1, MDISP_E_BADARG, "circle census radius must be >= 1");
+        CircleTaps tp;
+        for (int n = 0; n < npts; n++) {
+            // methods_disp.cpp:473-487, evaluated on the host in the reference's precision
+            float x = (float)(radius * cos(2.0 * 3.1415926535897932384626433832795 * n / (float)npts));
+            float y = (float)(-radius * sin(2.0 * 3.1415926535897932384626433832795 * n / (float)npts));
+            int fx = (int)floor(x), fy = (int)floor(y), cx = (int)ceil(x), cy = (int)ceil(y);
+            float tx = x - fx, ty = y - fy;
+            tp.fx[n] = fx; tp.fy[n] = fy; tp.cx[n] = cx; tp.cy[n] = cy;
+            tp.w1[n] = (1 - tx) * (1 - ty); tp.w2[n] = tx * (1 - ty); tp.w3[n] = (1 - tx) * ty; tp.w4[n] = tx * ty;
+        }
+        dim3 grid((W + 255) / 256, H);
+        census_circle_kernel<<<grid, 256, 0, s>>>(src, spitch, H, W, radius, npts, tp, dst, dpitch);
+        MD_HIP(hipGetLastError());
+        return MDISP_OK;
+    }
+    case MDISP_STATISTIC_MULTISCALE_CENSUS:
+        mdisp_set_error("STATISTIC_MULTISCALE_CENSUS (histogram rank remap) is not built yet");
+        return MDISP_E_UNSUPPORTED;
+    case MDISP_CENSUS_2017:
+        mdisp_set_error("CENSUS_2017 shifts past bit 31 and mutates shared state in the reference; not built");
+        return MDISP_E_UNSUPPORTED;
+    default:
+        mdisp_set_error("unknown census method %d", method);
+        return MDISP_E_BADARG;
+    }
+}
+
+int md_hamming(hipStream_t s, const u8* a, size_t ap, const u8* b, size_t bp, int H, int W, int32_t* dst, size_t dp)
+{
+    dim3 grid((W + 255) / 256, H);
+    hamming_kernel<<<grid, 256, 0, s>>>(a, ap, b, bp, H, W, dst, dp);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch)
+{
+    dim3 grid((W + 255) / 256, H);
+    bgr2gray_kernel<<<grid, 256, 0, s>>>(bgr, spitch, H, W, gray, dpitch);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}

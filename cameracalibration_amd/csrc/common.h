@@ -1,0 +1,81 @@
+// Shared declarations of libmdisp.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/mdisp.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+
+void mdisp_set_error(const char* fmt, ...);
+
+#define MD_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            mdisp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return MDISP_E_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define MD_REQUIRE(cond, code, ...)                  \
+    do {                                             \
+        if (!(cond)) {                               \
+            mdisp_set_error(__VA_ARGS__);            \
+            return (code);                           \
+        }                                            \
+    } while (0)
+
+struct mdisp_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    void* ws;            // grow-only device workspace
+    size_t ws_bytes;
+    bool timing;
+    hipEvent_t ev[6];    // [0,1] whole call, [2,3] SGM down sweep, [4,5] SGM up sweep
+    bool ev_valid[3];
+};
+
+// grow-only workspace; returns nullptr on failure (error set)
+void* mdisp_ws(mdisp_ctx* ctx, size_t bytes);
+
+static inline size_t md_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ static inline int md_align_dev(int v, int a) { return (v + a - 1) / a * a; }
+
+// ---- kernels' host launchers (all enqueue on `s`, no sync) ----
+// census.hip
+int md_pad_reflect_lr(hipStream_t s, const u8* src, size_t spitch, int H, int W, int left, int right, u8* dst, size_t dpitch);
+int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int method, int arg, u8* dst, size_t dpitch,
+              u8* scratch /* H*W bytes, needed by the MULTISCALE variants */);
+int md_hamming(hipStream_t s, const u8* a, size_t ap, const u8* b, size_t bp, int H, int W, int32_t* dst, size_t dp);
+int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch);
+
+// sgm.hip
+struct md_sgm_plan {
+    int H, W, D, minD, maxD, Wp;
+    int P1, P2, uniq, maxDiff, npaths, subpixel, costWin, census;
+    size_t off_cL, off_cR, off_pad, off_scratch, off_S, off_aux, total;
+    size_t pitchL, pitchR;
+};
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan);
+int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws);
+
+// stereo.hip
+int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
+                    int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op);
+// I: (H+1)*(W+1) ints, best: H*W ints of device scratch
+int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
+                int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best);
+int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, float thresh, u8* vL, u8* vR);
+int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
+             int dH, int dW, u8* dst, size_t dp);
+
+// cost kinds of md_cost_box_wta
+enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };
+// output kinds
+enum { MD_OUT_U8 = 0, MD_OUT_F64 = 1, MD_OUT_F32 = 2 };

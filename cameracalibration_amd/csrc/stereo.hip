@@ -1,0 +1,314 @@
+// Window-cost stereo kernels for gfx950: cost slice -> box aggregation -> winner-take-all fused in
+// one LDS-tiled kernel, the integral-image SAD variant, the LR consistency check and the
+// fixed-point bilinear remap.
+//
+// Replaces, in cameraCalibration/disp_method/methods_disp.cpp: the per-d absdiff / Hamming slices
+// (:232-234, :336-338, :969-975), sqrBoxFilter aggregation (:343-344, :383-384, :979-980), the
+// integral-image lookup (:238, :253-256), and the per-pixel minMaxLoc WTA loops (:246-262,
+// :350-363, :984-1000); in methods/patchmatch.cpp:817-828 the LR check; in methods/methods.cpp:1738,1745
+// cv::remap(INTER_LINEAR).
+#include "common.h"
+
+#define BT_X 64
+#define BT_Y 16
+
+__device__ __forceinline__ int reflect101_idx(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - p - 2;
+    return p;
+}
+
+struct BoxArgs {
+    const u8* ref; size_t rp;     // reference-view image (raw intensities or census codes), H x W
+    const u8* pad; size_t pp;     // other view padded by maxDisparity, H x Wp
+    int H, W, Wp;
+    int D, minD;                  // slice k <-> disparity minD + k
+    int off0, offStep;            // slice k compares ref(x) with pad(x + off0 + k*offStep)
+    int win, costKind, outKind;
+    void* out; size_t op;         // output pitch in elements
+    int RX, RY, SW, offmin;       // LDS tile geometry
+};
+
+__device__ __forceinline__ u32 pixel_cost(int kind, u32 r, u32 p)
+{
+    if (kind == MD_COST_HAMMING) return __popc(r ^ p);
+    if (kind == MD_COST_HAMMING_SQR) { u32 c = __popc(r ^ p); return c * c; }
+    u32 d = r > p ? r - p : p - r;
+    return kind == MD_COST_ABSDIFF_SQR ? d * d : d;
+}
+
+// One workgroup owns a BT_X x BT_Y tile of output pixels and loops over all D slices:
+//   A. per-pixel cost of the tile + halo from the LDS-resident input tiles  -> cost[] (u16)
+//   B. sliding horizontal window sums                                      -> hs[]   (u32)
+//   C. sliding vertical window sums, converted to float as the reference reads them
+//      (methods_disp.cpp:357,399,993) and compared with the running best (strict '<' = first min).
+// The window is centred with BORDER_REFLECT_101 applied to the cost slice, expressed through the
+// xmap/ymap index tables so only in-image costs are ever computed.
+__global__ __launch_bounds__(256) void cost_box_wta_kernel(BoxArgs a)
+{
+    extern __shared__ __align__(16) u8 smem[];
+    const int h = a.win / 2, RX = a.RX, RY = a.RY, SW = a.SW;
+    u8* refT = smem;                                             // [RY][RX]
+    u8* padT = refT + md_align_dev(RY * RX, 16);                 // [RY][SW]
+    u16* cost = reinterpret_cast<u16*>(padT + md_align_dev(RY * SW, 16));   // [RY][RX]
+    u32* hs = reinterpret_cast<u32*>(reinterpret_cast<u8*>(cost) + md_align_dev(RY * RX * 2, 16));   // [RY][BT_X]
+    short* xmap = reinterpret_cast<short*>(hs + RY * BT_X);      // [RX]
+    short* ymap = xmap + md_align_dev(RX, 8);                    // [RY]
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int gx0 = x0 - h, gy0 = y0 - h;
+    // reflected source position in tile coordinates; the clamp only ever acts on window taps of
+    // outputs that lie outside the image and are discarded
+    for (int i = tid; i < RX; i += 256) xmap[i] = (short)min(max(reflect101_idx(gx0 + i, a.W) - gx0, 0), RX - 1);
+    for (int i = tid; i < RY; i += 256) ymap[i] = (short)min(max(reflect101_idx(gy0 + i, a.H) - gy0, 0), RY - 1);
+    for (int i = tid; i < RY * RX; i += 256) {
+        int ry = i / RX, rx = i - ry * RX;
+        int gy = gy0 + ry, gx = gx0 + rx;
+        refT[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.ref[(size_t)gy * a.rp + gx] : 0;
+    }
+    for (int i = tid; i < RY * SW; i += 256) {
+        int ry = i / SW, sx = i - ry * SW;
+        int gy = gy0 + ry, px = gx0 + a.offmin + sx;
+        padT[i] = (gy >= 0 && gy < a.H && px >= 0 && px < a.Wp) ? a.pad[(size_t)gy * a.pp + px] : 0;
+    }
+    __syncthreads();
+
+    const int otx = tid & 63, oty = (tid >> 6) * 4;   // outputs (otx, oty .. oty+3)
+    float best[4];
+    int bestk[4] = {0, 0, 0, 0};
+    const int crx = tid & 127, cry0 = tid >> 7;        // stage A mapping: column crx, rows cry0, cry0+2, ...
+    const bool colIn = crx < RX && gx0 + crx >= 0 && gx0 + crx < a.W;
+
+    for (int k = 0; k < a.D; k++) {
+        const int rel = a.off0 + k * a.offStep - a.offmin;
+        if (colIn) {
+            for (int ry = cry0; ry < RY; ry += 2) {
+                int gy = gy0 + ry;
+                if (gy >= 0 && gy < a.H)
+                    cost[ry * RX + crx] = (u16)pixel_cost(a.costKind, refT[ry * RX + crx], padT[ry * SW + crx + rel]);
+            }
+        }
+        __syncthreads();
+        for (int task = tid; task < RY * 4; task += 256) {
+            const int ry = task >> 2, seg = task & 3;
+            const int gy = gy0 + ry;
+            if (gy >= 0 && gy < a.H) {
+                const u16* crow = cost + ry * RX;
+                int tx = seg * 16;
+                u32 s = 0;
+                for (int i = 0; i < a.win; i++) s += crow[xmap[tx + i]];
+                hs[ry * BT_X + tx] = s;
+                for (int j = 1; j < 16; j++) {
+                    s += crow[xmap[tx + j - 1 + a.win]];
+                    s -= crow[xmap[tx + j - 1]];
+                    hs[ry * BT_X + tx + j] = s;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            u32 s = 0;
+            for (int i = 0; i < a.win; i++) s += hs[ymap[oty + i] * BT_X + otx];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j > 0) {
+                    s += hs[ymap[oty + j - 1 + a.win] * BT_X + otx];
+                    s -= hs[ymap[oty + j - 1] * BT_X + otx];
+                }
+                const float c = (float)s;
+                if (k == 0 || c < best[j]) { best[j] = c; bestk[j] = k; }
+            }
+        }
+        // the next iteration's stage-A writes touch cost[] only; hs[] is rewritten after its barrier
+    }
+    const int gx = x0 + otx;
+    if (gx < a.W) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gy = y0 + oty + j;
+            if (gy >= a.H) break;
+            const int d = bestk[j] + a.minD;
+            if (a.outKind == MD_OUT_U8) reinterpret_cast<u8*>(a.out)[(size_t)gy * a.op + gx] = (u8)(d & 0xFF);
+            else if (a.outKind == MD_OUT_F64) reinterpret_cast<double*>(a.out)[(size_t)gy * a.op + gx] = (double)d;
+            else reinterpret_cast<float*>(a.out)[(size_t)gy * a.op + gx] = (float)d;
+        }
+    }
+}
+
+int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
+                    int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op)
+{
+    BoxArgs a;
+    a.ref = ref; a.rp = rp; a.pad = pad; a.pp = pp; a.H = H; a.W = W; a.Wp = W + maxD;
+    a.D = maxD - minD + 1; a.minD = minD; a.off0 = off0; a.offStep = offStep;
+    a.win = win; a.costKind = costKind; a.outKind = outKind; a.out = out; a.op = op;
+    const int h = win / 2;
+    a.RX = BT_X + 2 * h; a.RY = BT_Y + 2 * h;
+    const int offLast = off0 + offStep * (a.D - 1);
+    a.offmin = off0 < offLast ? off0 : offLast;
+    const int offmax = off0 < offLast ? offLast : off0;
+    a.SW = a.RX + (offmax - a.offmin);
+    MD_REQUIRE(a.RX <= 128, MDISP_E_BADARG, "winSize %d too large for the box kernel (max 65)", win);
+    size_t lds = md_align((size_t)a.RY * a.RX, 16) + md_align((size_t)a.RY * a.SW, 16) +
+                 md_align((size_t)a.RY * a.RX * 2, 16) + (size_t)a.RY * BT_X * 4 +
+                 md_align((size_t)a.RX, 8) * 2 + (size_t)a.RY * 2 + 64;
+    MD_REQUIRE(lds <= 160 * 1024, MDISP_E_RANGE, "box kernel needs %zu bytes of LDS (max 163840)", lds);
+    if (lds > 64 * 1024)
+        MD_HIP(hipFuncSetAttribute((const void*)cost_box_wta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((W + BT_X - 1) / BT_X, (H + BT_Y - 1) / BT_Y);
+    cost_box_wta_kernel<<<grid, 256, lds, s>>>(a);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Integral-image SAD (computeSAD_inteOpti, methods_disp.cpp:207-309) with exact integer tables.
+// Footprint and zero-outside rule are the reference's: cost = I(x+h,y+h) - I(x+h,y-h) - I(x-h,y+h)
+// + I(x-h,y-h) on the (H+1)x(W+1) table, any corner whose index falls outside the table reads 0
+// (getMatVal, :159-171) -- so the window is 2h x 2h and the last h columns/rows produce the
+// reference's negative "garbage" costs, reproduced here exactly.
+
+// exclusive row prefix of |ref - pad(x+off)|: P[y][x] = sum_{x' < x} diff, x in [0, W]
+__global__ __launch_bounds__(256) void sad_row_prefix_kernel(const u8* __restrict__ ref, size_t rp, const u8* __restrict__ pad,
+                                                             size_t pp, int W, int off, int* __restrict__ P, int PW)
+{
+    __shared__ int part[256];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const int chunk = (W + 255) / 256;
+    const int xb = tid * chunk, xe = min(W, xb + chunk);
+    const u8* r = ref + (size_t)y * rp;
+    const u8* p = pad + (size_t)y * pp + off;
+    int s = 0;
+    for (int x = xb; x < xe; x++) { int a = r[x], b = p[x]; s += a > b ? a - b : b - a; }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;   // exclusive prefix of this thread's chunk
+    int* row = P + (size_t)y * PW;
+    for (int x = xb; x < xe; x++) {
+        row[x] = run;
+        int a = r[x], b = p[x];
+        run += a > b ? a - b : b - a;
+    }
+    if (xe == W && xb < W) row[W] = run;
+    if (W == 0 && tid == 0) row[0] = 0;
+}
+
+// in-place column prefix: I[y+1][x] = sum_{y' <= y} P[y'][x]; row 0 of I is zero.  I has H+1 rows.
+__global__ __launch_bounds__(256) void sad_col_prefix_kernel(int* __restrict__ I, int H, int PW)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= PW) return;
+    int run = 0;
+    // rows are stored shifted by one: input row y lives at I[(y+1)*PW]
+    for (int y = 1; y <= H; y++) {
+        run += I[(size_t)y * PW + x];
+        I[(size_t)y * PW + x] = run;
+    }
+    I[x] = 0;
+}
+
+__global__ __launch_bounds__(256) void sad_inte_wta_kernel(const int* __restrict__ I, int H, int W, int PW, int h, int k, int d,
+                                                           int* __restrict__ best, u8* __restrict__ out, size_t op)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    auto get = [&](int xx, int yy) -> int {
+        return (xx >= 0 && xx <= W && yy >= 0 && yy <= H) ? I[(size_t)yy * PW + xx] : 0;
+    };
+    const int c = get(x + h, y + h) - get(x + h, y - h) - get(x - h, y + h) + get(x - h, y - h);
+    const size_t i = (size_t)y * W + x;
+    if (k == 0 || c < best[i]) { best[i] = c; out[(size_t)y * op + x] = (u8)(d & 0xFF); }
+}
+
+int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
+                int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best)
+{
+    MD_REQUIRE((double)H * W * 255.0 < 2147483647.0, MDISP_E_RANGE, "integral table overflows 32 bits for %dx%d", W, H);
+    const int PW = W + 1, D = maxD - minD + 1;
+    for (int k = 0; k < D; k++) {
+        const int off = off0 + k * offStep;
+        sad_row_prefix_kernel<<<H, 256, 0, s>>>(ref, rp, pad, pp, W, off, I + PW, PW);
+        sad_col_prefix_kernel<<<(PW + 255) / 256, 256, 0, s>>>(I, H, PW);
+        dim3 grid((W + 255) / 256, H);
+        sad_inte_wta_kernel<<<grid, 256, 0, s>>>(I, H, W, PW, win / 2, k, minD + k, best, out, op);
+    }
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PatchMatch::postProcess validity test, methods/patchmatch.cpp:817-828 (the right-view clamp uses
+// `rows` as the reference does; an index of `cols` is clamped to the last column).
+__global__ __launch_bounds__(256) void lr_check_kernel(const float* __restrict__ dL, const float* __restrict__ dR, int H, int W,
+                                                       float thresh, u8* __restrict__ vL, u8* __restrict__ vR)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t row = (size_t)y * W;
+    const float a = dL[row + x];
+    int xr = (int)fmaxf(0.f, fminf((float)W, (float)x - a));
+    xr = min(xr, W - 1);
+    vL[row + x] = (u8)(fabsf(a - dR[row + xr]) <= thresh);
+    const float b = dR[row + x];
+    int xl = (int)fmaxf(0.f, fminf((float)H, (float)x + b));
+    xl = min(xl, W - 1);
+    vR[row + x] = (u8)(fabsf(b - dL[row + xl]) <= thresh);
+}
+
+int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, float thresh, u8* vL, u8* vR)
+{
+    dim3 grid((W + 255) / 256, H);
+    lr_check_kernel<<<grid, 256, 0, s>>>(dL, dR, H, W, thresh, vL, vR);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::remap(INTER_LINEAR) for 8-bit images with CV_16SC2 + CV_16UC1 fixed-point maps:
+// 5 fractional bits, int16 weights summing to 32768, (sum + 2^14) >> 15, constant-0 border.
+// One thread per destination pixel; map reads are coalesced, the four taps are gathered.
+template <int CN>
+__global__ __launch_bounds__(256) void remap_kernel(const u8* __restrict__ src, size_t sp, int sH, int sW,
+                                                    const int16_t* __restrict__ m1, const u16* __restrict__ m2,
+                                                    int dH, int dW, u8* __restrict__ dst, size_t dp)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dW) return;
+    const size_t i = (size_t)y * dW + x;
+    const u32 xy = reinterpret_cast<const u32*>(m1)[i];
+    const int sx = (int16_t)(xy & 0xFFFF), sy = (int16_t)(xy >> 16);
+    const int f = m2[i] & 1023;
+    const int fa = f & 31, fb = f >> 5;
+    int w0 = (32 - fa) * (32 - fb) * 32, w1 = fa * (32 - fb) * 32, w2 = (32 - fa) * fb * 32, w3 = fa * fb * 32;
+    if (w0 > 32767) { w0 = 32767; w3 += 1; }   // int16 saturation of the (0,0) entry and its sum correction
+    const bool x0ok = sx >= 0 && sx < sW, x1ok = sx + 1 >= 0 && sx + 1 < sW;
+    const bool y0ok = sy >= 0 && sy < sH, y1ok = sy + 1 >= 0 && sy + 1 < sH;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        int p00 = (x0ok && y0ok) ? src[(size_t)sy * sp + (size_t)sx * CN + c] : 0;
+        int p01 = (x1ok && y0ok) ? src[(size_t)sy * sp + (size_t)(sx + 1) * CN + c] : 0;
+        int p10 = (x0ok && y1ok) ? src[(size_t)(sy + 1) * sp + (size_t)sx * CN + c] : 0;
+        int p11 = (x1ok && y1ok) ? src[(size_t)(sy + 1) * sp + (size_t)(sx + 1) * CN + c] : 0;
+        int r = (p00 * w0 + p01 * w1 + p10 * w2 + p11 * w3 + (1 << 14)) >> 15;
+        dst[(size_t)y * dp + (size_t)x * CN + c] = (u8)min(max(r, 0), 255);
+    }
+}
+
+int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
+             int dH, int dW, u8* dst, size_t dp)
+{
+    dim3 grid((dW + 255) / 256, dH);
+    if (cn == 1) remap_kernel<1><<<grid, 256, 0, s>>>(src, sp, sH, sW, m1, m2, dH, dW, dst, dp);
+    else if (cn == 3) remap_kernel<3><<<grid, 256, 0, s>>>(src, sp, sH, sW, m1, m2, dH, dW, dst, dp);
+    else { mdisp_set_error("remap supports 1 or 3 channels, got %d", cn); return MDISP_E_BADARG; }
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}

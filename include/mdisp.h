@@ -1,0 +1,210 @@
+/*
+ * mdisp -- C ABI of the MI355X (gfx950) dense-stereo disparity library, libmdisp.so.
+ *
+ * Every entry point replaces one function (or one OpenCV call site) of the reference's dense
+ * stereo path; the reference interface is cited as file:line relative to
+ * cameraCalibration/ in the reference repository.  Signatures use plain pointers and sizes only.
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative MDISP_E_* code; they never throw.
+ *   - "host" entry points take host buffers (what a cv::Mat holds), copy in, compute on the GPU and
+ *     copy the result back into a caller-allocated output image.
+ *   - "_dev" entry points take device pointers that are already resident in HBM and enqueue the
+ *     work on the context's stream without synchronising; outputs stay on the device.
+ *   - a context owns one HIP stream and a grow-only device workspace; calls on one context are
+ *     serialised by that stream, two contexts may be used concurrently from two host threads (the
+ *     reference calls its L and R disparity routines from two std::async threads,
+ *     cameraCalibration.cpp:163-190).
+ *   - there is no CPU fallback: without a HIP device every compute entry point fails with
+ *     MDISP_E_NODEVICE.
+ */
+#ifndef MDISP_H
+#define MDISP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ---- */
+#define MDISP_OK            0
+#define MDISP_E_BADARG     -1   /* null pointer, size mismatch, even winSize, bad enum ...        */
+#define MDISP_E_NODEVICE   -2   /* no HIP device / HIP runtime error at context creation        */
+#define MDISP_E_HIP        -3   /* a HIP call failed; see mdisp_last_error()                     */
+#define MDISP_E_UNSUPPORTED -4  /* e.g. CENSUS_2017, which is undefined behaviour in the reference */
+#define MDISP_E_RANGE      -5   /* parameters overflow the 16-bit path-cost range                */
+#define MDISP_E_NOMEM      -6
+
+/* ---- pixel depths (numeric values equal OpenCV's CV_8U ... CV_64F) ---- */
+#define MDISP_8U  0
+#define MDISP_8S  1
+#define MDISP_16U 2
+#define MDISP_16S 3
+#define MDISP_32S 4
+#define MDISP_32F 5
+#define MDISP_64F 6
+
+/* POD view of a cv::Mat (data, rows, cols, channels(), depth(), step[0]). */
+typedef struct mdisp_image {
+    void* data;
+    int rows, cols, channels, depth;
+    size_t step_bytes;
+} mdisp_image;
+
+/* StereoMatchParam without the images, disp_method/methods_disp.h:5-16.
+ * maxDisparity is INCLUSIVE: numDisp = maxDisparity - minDisparity + 1 (methods_disp.cpp:219). */
+typedef struct mdisp_param {
+    int winSize;
+    int minDisparity;
+    int maxDisparity;
+    int isDispLeft;
+} mdisp_param;
+
+/* CENSUS_ALGORITHM, disp_method/methods_disp.h:18-27 (same numeric values). */
+enum {
+    MDISP_BASIC_CENSUS = 0,
+    MDISP_CIRCLE_CENSUS = 1,
+    MDISP_ROTATION_INVARIANT_CENSUS = 2,
+    MDISP_UNIFORM_CENSUS = 3,
+    MDISP_MULTISCALE_CENSUS = 4,
+    MDISP_STATISTIC_MULTISCALE_CENSUS = 5,
+    MDISP_CENSUS_2017 = 6
+};
+
+/* Aggregation of each Hamming slice inside censusStereo (methods_disp.cpp:969-982).  GUIDED is
+ * what the reference runs (getGuidedFilter(img, slice, winSize, 1e-6), :978); SQRBOX is the
+ * alternative left in its comments (:979-980); BOX and NONE are the integer-exact modes. */
+enum {
+    MDISP_AGG_NONE = 0,
+    MDISP_AGG_BOX = 1,
+    MDISP_AGG_SQRBOX = 2,
+    MDISP_AGG_GUIDED = 3
+};
+
+/* GIF_TYPE, disp_method/gifs.h:4-13 (same numeric values for the built ones). */
+enum {
+    MDISP_GIF = 0,
+    MDISP_WGIF = 1,
+    MDISP_EGIF = 2,
+    MDISP_SKWGIF = 3
+};
+
+/* cost source of mdisp_asw_gifs */
+enum {
+    MDISP_COST_VOLUME = 0,   /* caller supplies D float slices (what computeDisp_Feature returns)  */
+    MDISP_COST_CENSUS = 1,   /* Hamming distance of BASIC_CENSUS codes, as in censusStereo         */
+    MDISP_COST_ABSDIFF = 2   /* |L - R shifted|, as in computeSAD_* (methods_disp.cpp:232-234)      */
+};
+
+/* Parameters of cv::StereoSGBM::create as used at methods/methods.cpp:1893 and :1216-1219, plus
+ * the choice of matching cost.  Zero / negative values select StereoSGBM's defaults
+ * (P1 -> 2, P2 -> max(5, P1+1), uniquenessRatio -> 10, disp12MaxDiff -> 1). */
+typedef struct mdisp_sgbm_params {
+    int minDisparity;
+    int numDisparities;     /* a COUNT (unlike mdisp_param.maxDisparity)                         */
+    int P1, P2;
+    int uniquenessRatio;
+    int disp12MaxDiff;
+    int paths;              /* 8 (all directions), 5 (MODE_SGBM set) or 4 (axis-aligned)         */
+    int subpixel;           /* 1: x16 parabola refinement, 0: disparity*16                        */
+    int costWin;            /* 1: per-pixel Hamming cost; odd >1: box-summed over costWin^2       */
+    int censusMethod;       /* MDISP_BASIC_CENSUS / ROTATION_INVARIANT / UNIFORM                  */
+} mdisp_sgbm_params;
+
+typedef struct mdisp_ctx mdisp_ctx;
+
+/* ---- library / context ---- */
+int         mdisp_version(void);
+const char* mdisp_last_error(void);              /* thread-local message of the last failure    */
+int         mdisp_device_count(void);
+/* device < 0 selects the current HIP device.  stream: a hipStream_t to enqueue on, or NULL to
+ * let the context create its own. */
+int  mdisp_create(mdisp_ctx** ctx, int device, void* stream);
+void mdisp_destroy(mdisp_ctx* ctx);
+int  mdisp_synchronize(mdisp_ctx* ctx);
+
+/* ---- census family: countCensusImg*, methods_disp.cpp:415-714 ----
+ * dst is CV_8U of src's size.  `arg` is the radius for CIRCLE and the window for the
+ * MULTISCALE variants, ignored otherwise. */
+int mdisp_census_transform(mdisp_ctx*, const mdisp_image* src, int method, int arg, mdisp_image* dst);
+
+/* countHummingDist, methods_disp.cpp:808-838: two CV_8U images -> CV_32S popcount(a ^ b). */
+int mdisp_hamming_dist(mdisp_ctx*, const mdisp_image* a, const mdisp_image* b, mdisp_image* dst);
+
+/* censusStereo(StereoMatchParam, CENSUS_ALGORITHM), methods_disp.h:62, methods_disp.cpp:845-1145.
+ * L/R: CV_8UC1 or CV_8UC3 (BGR, converted as checkImg does, :130-147).  out: CV_64F HxW. */
+int mdisp_census_stereo(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p,
+                        int census_method, int agg_mode, mdisp_image* out);
+
+/* computeSAD_inteOpti / computeSAD_BFOpti, methods_disp.h:43-44, methods_disp.cpp:207-408.
+ * out: CV_8U HxW (value stored modulo 256 like the reference's .at<char>). */
+int mdisp_sad_inte(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
+int mdisp_sad_box(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
+
+/* getGuidedFilter / _wgif / _egif / _skwgif2, gifs.h:17-33, gifs.cpp:47-135,227-273,376-409,537-617.
+ * guide: CV_8UC1, P: CV_8U / CV_32S / CV_32F single channel, out (and beta): CV_32F.
+ * steerW: CV_64F map from mdisp_steer_filter (SKWGIF only).  beta may be NULL. */
+int mdisp_guided_filter(mdisp_ctx*, const mdisp_image* guide, const mdisp_image* P, int r, double eps,
+                        int gif_type, const mdisp_image* steerW, int r2, double namuda,
+                        mdisp_image* out, mdisp_image* beta);
+
+/* steerFilter(src, dst), steerFilter.h:39, steerFilter.cpp:239-446.  src CV_8UC1, dst CV_64F. */
+int mdisp_steer_filter(mdisp_ctx*, const mdisp_image* src, mdisp_image* dst);
+
+/* asw_gifs(StereoMatchParam, eps, GIF_TYPE, r2, namda, h), methods_disp.h:66, methods_disp.cpp:1147-1297.
+ * cost_source MDISP_COST_VOLUME: `costs` points to numDisp contiguous CV_32F HxW slices (the
+ * output of computeDisp_Feature, which stays on the caller's side); otherwise costs is NULL and
+ * the slices are computed on the GPU.  out: CV_32F HxW. */
+int mdisp_asw_gifs(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p,
+                   double eps, int gif_type, int r2, double namda, double h,
+                   int cost_source, const float* costs, mdisp_image* out);
+
+/* getDisparity_SGBM / cv::StereoSGBM::compute call sites, methods/methods.cpp:1883-1921,1216-1219,1291.
+ * L/R CV_8UC1; out CV_16S HxW, fixed point x16, invalid = (minDisparity-1)*16. */
+int mdisp_sgbm(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out);
+
+/* LR consistency check of PatchMatch::postProcess, methods/patchmatch.cpp:817-828.
+ * dL/dR CV_32F, validL/validR CV_8U (1 = consistent within `thresh`). */
+int mdisp_lr_check(mdisp_ctx*, const mdisp_image* dL, const mdisp_image* dR, float thresh,
+                   mdisp_image* validL, mdisp_image* validR);
+
+/* cv::initUndistortRectifyMap(K, D, R, P, size, CV_16SC2, map1, map2), methods/methods.cpp:1705-1706.
+ * Host-side double arithmetic.  map1: int16 x2 per pixel, map2: uint16 per pixel. */
+int mdisp_build_rectify_maps(const double K[9], const double* dist, int ndist, const double R[9],
+                             const double P[12], int width, int height, int16_t* map1, uint16_t* map2);
+
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR), methods/methods.cpp:1738,1745.
+ * src/dst CV_8UC1 or CV_8UC3; maps as produced above, of dst's size. */
+int mdisp_remap(mdisp_ctx*, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst);
+
+/* ---- device-resident entry points (inputs already in HBM, nothing copied, no sync) ---- */
+
+/* bytes of device workspace mdisp_sgbm_dev needs for one pair */
+size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p);
+
+/* d_left/d_right: device CV_8UC1 with the given pitch; d_disp: device int16 HxW (pitch = cols*2).
+ * d_workspace: at least mdisp_sgbm_workspace_bytes() of device memory, or NULL to use the
+ * context's own workspace. */
+int mdisp_sgbm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                   const mdisp_sgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
+
+/* census stereo on device buffers; d_disp: device double HxW */
+int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                            const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
+
+/* time of the most recent call's dominant kernel on this context, measured with HIP events on
+ * the context's stream (milliseconds); which = 0: whole call, 1: SGM down sweep, 2: SGM up sweep */
+int mdisp_last_kernel_ms(mdisp_ctx*, int which, float* ms);
+int mdisp_enable_timing(mdisp_ctx*, int on);
+
+/* ---- synthetic rectified pair generator used by the tests and the benchmark (host) ----
+ * right = box-filtered white noise, left(x,y) = right(reflect(x - d_gt), y) + noise in [-2,2];
+ * gt (nullable) receives the piecewise-planar ground-truth disparity. */
+int mdisp_synth_pair(uint32_t seed, int rows, int cols, int numDisp, uint8_t* left, uint8_t* right, uint16_t* gt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDISP_H */

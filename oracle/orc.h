@@ -1,0 +1,126 @@
+/*
+ * CPU oracle for the dense-stereo hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's CPU algorithms (census /
+ * Hamming / SAD / box and guided aggregation / WTA / SGM recursion / LR check /
+ * remap).  It is never linked into, imported by or called from the shipped
+ * library; only the test-suite, the smoke check and the benchmark's CPU-baseline
+ * leg use it, and there only as the checker.
+ *
+ * PARITY UNPINNED: the reference cannot be compiled here (OpenCV, PCL and CImg
+ * are absent) and it ships no tests, golden vectors or expected outputs.  The
+ * functions below follow the reference source text line by line where the
+ * reference owns the arithmetic, and the documented OpenCV 4.1.0 semantics where
+ * it only calls into OpenCV.  What pins them: hand-derivable known answers
+ * (constant image, ramps, identical pairs), independent numpy/scipy
+ * re-derivations in tests/, and the stereoRectify outputs stored in
+ * cameraCalibration/unditortStereoCalib.xml.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* census variants, cameraCalibration/disp_method/methods_disp.h:18-27 */
+enum {
+    ORC_BASIC_CENSUS = 0,
+    ORC_CIRCLE_CENSUS = 1,
+    ORC_ROTATION_INVARIANT_CENSUS = 2,
+    ORC_UNIFORM_CENSUS = 3,
+    ORC_MULTISCALE_CENSUS = 4,
+    ORC_STATISTIC_MULTISCALE_CENSUS = 5,
+    ORC_CENSUS_2017 = 6
+};
+
+/* aggregation applied to each Hamming slice inside census stereo */
+enum {
+    ORC_AGG_NONE = 0,      /* raw per-pixel Hamming distance                              */
+    ORC_AGG_BOX = 1,       /* integer box sum, win x win, BORDER_REFLECT_101              */
+    ORC_AGG_SQRBOX = 2,    /* integer box sum of squares (the commented sqrBoxFilter)     */
+    ORC_AGG_GUIDED = 3     /* getGuidedFilter(guide, slice, win, 1e-6): the active path   */
+};
+
+enum { ORC_SAT_F32 = 0, ORC_SAT_INT = 1 };
+
+enum {
+    ORC_GIF = 0, ORC_WGIF = 1, ORC_EGIF = 2, ORC_SKWGIF = 3
+};
+
+typedef struct {
+    int minDisparity;
+    int numDisparities;
+    int P1, P2;
+    int uniquenessRatio;   /* percent; <0 disables the test                                */
+    int disp12MaxDiff;     /* <0 disables the LR check                                     */
+    int paths;             /* 8, 5 (MODE_SGBM order) or 4                                  */
+    int subpixel;          /* 1: x16 parabola refinement                                   */
+    int costWin;           /* odd box window summed over the Hamming cost (1 = per pixel)  */
+    int censusMethod;
+} orc_sgm_params;
+
+/* ---- borders / colour ---- */
+int  orc_reflect(int p, int n);        /* BORDER_REFLECT     fedcba|abcdef|fedcba */
+int  orc_reflect101(int p, int n);     /* BORDER_REFLECT_101 gfedcb|abcdef|edcba  */
+void orc_pad_reflect_lr(const uint8_t* src, int H, int W, int left, int right, uint8_t* dst);
+void orc_bgr2gray(const uint8_t* bgr, int H, int W, uint8_t* gray);
+
+/* ---- census family / Hamming ---- */
+void orc_census_basic(const uint8_t* src, int H, int W, uint8_t* dst);
+void orc_census_rotation_inv(const uint8_t* src, int H, int W, uint8_t* dst);
+void orc_census_uniform(const uint8_t* src, int H, int W, uint8_t* dst);
+void orc_census_multiscale(const uint8_t* src, int H, int W, int scale, uint8_t* dst);
+void orc_census_multiscale2(const uint8_t* src, int H, int W, int scale, uint8_t* dst);
+void orc_census_circle(const uint8_t* src, int H, int W, int radius, int npts, uint8_t* dst);
+int  orc_census(const uint8_t* src, int H, int W, int method, int winSize, int isPaddedView, uint8_t* dst);
+void orc_ri_table(uint8_t* t256);
+void orc_uniform_table(uint8_t* t256);
+int  orc_hop_count(uint8_t v);
+void orc_hamming(const uint8_t* a, const uint8_t* b, long n, int32_t* dst);
+
+/* ---- stereo drivers ---- */
+int orc_census_stereo(const uint8_t* L, const uint8_t* R, int H, int W, int winSize, int minD, int maxD,
+                      int isDispLeft, int method, int agg, double* disp, float* costVolume /*nullable: D*H*W*/);
+int orc_sad_inte(const uint8_t* L, const uint8_t* R, int H, int W, int winSize, int minD, int maxD,
+                 int isDispLeft, int satMode, uint8_t* disp);
+int orc_sad_box(const uint8_t* L, const uint8_t* R, int H, int W, int winSize, int minD, int maxD,
+                int isDispLeft, uint8_t* disp);
+
+/* ---- filters ---- */
+void orc_box_filter_f32(const float* src, int H, int W, int kw, int kh, int normalize, float* dst);
+void orc_box_sum_u32(const uint32_t* src, int H, int W, int kw, int kh, uint32_t* dst);
+void orc_normalize_minmax_u8(const uint8_t* src, long n, float* dst);
+void orc_normalize_minmax_s32(const int32_t* src, long n, float* dst);
+void orc_normalize_minmax_f32(const float* src, long n, float* dst);
+void orc_guided_filter(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out);
+void orc_guided_filter_egif(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out, float* beta);
+void orc_guided_filter_wgif(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out);
+void orc_guided_filter_skwgif2(const float* guideN, const float* pN, const double* steerW, int H, int W,
+                               int r, int r2, double eps, double namuda, float* out);
+void orc_steer_filter(const uint8_t* src, int H, int W, double* dst);
+int  orc_asw_gifs(const uint8_t* guide, const float* costs /*D*H*W f32*/, int H, int W, int D, int minD,
+                  int winSize, double eps, int gifType, int r2, double namuda, float* disp, float* filtered /*nullable*/);
+
+/* ---- SGM ---- */
+int orc_sgm(const uint8_t* L, const uint8_t* R, int H, int W, const orc_sgm_params* p,
+            int16_t* disp, uint16_t* Svol /*nullable: H*W*D*/);
+
+/* ---- LR check (patchmatch.cpp:817-828) ---- */
+void orc_lr_check(const float* dL, const float* dR, int H, int W, float thresh, uint8_t* validL, uint8_t* validR);
+
+/* ---- rectification ---- */
+void orc_init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double R[9],
+                                    const double P[12], int W, int H, int16_t* map1, uint16_t* map2);
+void orc_remap_bilinear_u8(const uint8_t* src, int sH, int sW, int cn, const int16_t* map1, const uint16_t* map2,
+                           int dH, int dW, uint8_t* dst);
+void orc_stereo_rectify(const double K1[9], const double* D1, const double K2[9], const double* D2, int ndist,
+                        int W, int H, const double R[9], const double T[3],
+                        double R1[9], double R2[9], double P1[12], double P2[12], double Q[16],
+                        int roi1[4], int roi2[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,255 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+cpu_baseline leg, never by the shipped package.  Parity is unpinned against the real reference
+(it cannot be built here; see oracle/orc.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liborc.so")
+
+BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS, \
+    STATISTIC_MULTISCALE_CENSUS, CENSUS_2017 = range(7)
+AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
+SAT_F32, SAT_INT = 0, 1
+GIF, WGIF, EGIF, SKWGIF = range(4)
+
+
+class orc_sgm_params(C.Structure):
+    _fields_ = [("minDisparity", C.c_int), ("numDisparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
+                ("uniquenessRatio", C.c_int), ("disp12MaxDiff", C.c_int), ("paths", C.c_int), ("subpixel", C.c_int),
+                ("costWin", C.c_int), ("censusMethod", C.c_int)]
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def pad_reflect_lr(src, left, right):
+    src = _u8(src)
+    H, W = src.shape
+    dst = np.empty((H, W + left + right), np.uint8)
+    lib().orc_pad_reflect_lr(_p(src), H, W, left, right, _p(dst))
+    return dst
+
+
+def bgr2gray(bgr):
+    bgr = _u8(bgr)
+    H, W, _ = bgr.shape
+    g = np.empty((H, W), np.uint8)
+    lib().orc_bgr2gray(_p(bgr), H, W, _p(g))
+    return g
+
+
+def census(src, method=BASIC_CENSUS, arg=0):
+    src = _u8(src)
+    H, W = src.shape
+    dst = np.empty((H, W), np.uint8)
+    L = lib()
+    if method == BASIC_CENSUS:
+        L.orc_census_basic(_p(src), H, W, _p(dst))
+    elif method == ROTATION_INVARIANT_CENSUS:
+        L.orc_census_rotation_inv(_p(src), H, W, _p(dst))
+    elif method == UNIFORM_CENSUS:
+        L.orc_census_uniform(_p(src), H, W, _p(dst))
+    elif method == MULTISCALE_CENSUS:
+        L.orc_census_multiscale(_p(src), H, W, arg, _p(dst))
+    elif method == STATISTIC_MULTISCALE_CENSUS:
+        L.orc_census_multiscale2(_p(src), H, W, arg, _p(dst))
+    elif method == CIRCLE_CENSUS:
+        L.orc_census_circle(_p(src), H, W, arg, 8, _p(dst))
+    else:
+        raise ValueError("unsupported census method")
+    return dst
+
+
+def ri_table():
+    t = np.empty(256, np.uint8)
+    lib().orc_ri_table(_p(t))
+    return t
+
+
+def uniform_table():
+    t = np.empty(256, np.uint8)
+    lib().orc_uniform_table(_p(t))
+    return t
+
+
+def hamming(a, b):
+    a, b = _u8(a), _u8(b)
+    dst = np.empty(a.shape, np.int32)
+    lib().orc_hamming(_p(a), _p(b), C.c_long(a.size), _p(dst))
+    return dst
+
+
+def census_stereo(L, R, winSize, minD, maxD, isDispLeft=True, method=BASIC_CENSUS, agg=AGG_GUIDED, want_costs=False):
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    disp = np.empty((H, W), np.float64)
+    costs = np.empty((maxD - minD + 1, H, W), np.float32) if want_costs else None
+    rc = lib().orc_census_stereo(_p(L), _p(R), H, W, winSize, minD, maxD, int(isDispLeft), method, agg, _p(disp),
+                                 _p(costs) if want_costs else None)
+    if rc:
+        return (None, None) if want_costs else None
+    return (disp, costs) if want_costs else disp
+
+
+def sad_inte(L, R, winSize, minD, maxD, isDispLeft=True, sat=SAT_INT):
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    disp = np.empty((H, W), np.uint8)
+    rc = lib().orc_sad_inte(_p(L), _p(R), H, W, winSize, minD, maxD, int(isDispLeft), sat, _p(disp))
+    return None if rc else disp
+
+
+def sad_box(L, R, winSize, minD, maxD, isDispLeft=True):
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    disp = np.empty((H, W), np.uint8)
+    rc = lib().orc_sad_box(_p(L), _p(R), H, W, winSize, minD, maxD, int(isDispLeft), _p(disp))
+    return None if rc else disp
+
+
+def box_filter_f32(src, kw, kh, normalize=True):
+    src = np.ascontiguousarray(src, np.float32)
+    H, W = src.shape
+    dst = np.empty((H, W), np.float32)
+    lib().orc_box_filter_f32(_p(src), H, W, kw, kh, int(normalize), _p(dst))
+    return dst
+
+
+def normalize_minmax(src):
+    src = np.ascontiguousarray(src)
+    dst = np.empty(src.shape, np.float32)
+    n = C.c_long(src.size)
+    if src.dtype == np.uint8:
+        lib().orc_normalize_minmax_u8(_p(src), n, _p(dst))
+    elif src.dtype == np.int32:
+        lib().orc_normalize_minmax_s32(_p(src), n, _p(dst))
+    elif src.dtype == np.float32:
+        lib().orc_normalize_minmax_f32(_p(src), n, _p(dst))
+    else:
+        raise TypeError(src.dtype)
+    return dst
+
+
+def steer_filter(src):
+    src = _u8(src)
+    H, W = src.shape
+    dst = np.empty((H, W), np.float64)
+    lib().orc_steer_filter(_p(src), H, W, _p(dst))
+    return dst
+
+
+def guided_filter(guide, P, r, eps, gif_type=GIF, steerW=None, r2=5, namuda=0.1, want_beta=False):
+    """guide: uint8, P: uint8 / int32 / float32 (normalised here as the reference does)."""
+    G = normalize_minmax(_u8(guide))
+    Pn = normalize_minmax(np.ascontiguousarray(P))
+    H, W = G.shape
+    out = np.empty((H, W), np.float32)
+    L = lib()
+    d = C.c_double
+    if gif_type == GIF:
+        L.orc_guided_filter(_p(G), _p(Pn), H, W, r, d(eps), _p(out))
+    elif gif_type == WGIF:
+        L.orc_guided_filter_wgif(_p(G), _p(Pn), H, W, r, d(eps), _p(out))
+    elif gif_type == EGIF:
+        beta = np.empty((H, W), np.float32)
+        L.orc_guided_filter_egif(_p(G), _p(Pn), H, W, r, d(eps), _p(out), _p(beta))
+        if want_beta:
+            return out, beta
+    elif gif_type == SKWGIF:
+        sw = np.ascontiguousarray(steerW, np.float64)
+        L.orc_guided_filter_skwgif2(_p(G), _p(Pn), _p(sw), H, W, r, r2, d(eps), d(namuda), _p(out))
+    else:
+        raise ValueError(gif_type)
+    return out
+
+
+def asw_gifs(guide, costs, minD, winSize, eps, gif_type=GIF, r2=5, namuda=0.1, want_filtered=False):
+    guide = _u8(guide)
+    costs = np.ascontiguousarray(costs, np.float32)
+    D, H, W = costs.shape
+    disp = np.empty((H, W), np.float32)
+    filt = np.empty((D, H, W), np.float32) if want_filtered else None
+    rc = lib().orc_asw_gifs(_p(guide), _p(costs), H, W, D, minD, winSize, C.c_double(eps), gif_type, r2,
+                            C.c_double(namuda), _p(disp), _p(filt) if want_filtered else None)
+    if rc:
+        return None
+    return (disp, filt) if want_filtered else disp
+
+
+def sgm(L, R, minD=0, D=64, P1=0, P2=0, uniq=-1, maxDiff=0, paths=8, subpixel=1, costWin=1, census_method=BASIC_CENSUS,
+        want_S=False):
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    p = orc_sgm_params(minD, D, P1, P2, uniq, maxDiff, paths, subpixel, costWin, census_method)
+    disp = np.empty((H, W), np.int16)
+    S = np.empty((H, W, D), np.uint16) if want_S else None
+    rc = lib().orc_sgm(_p(L), _p(R), H, W, C.byref(p), _p(disp), _p(S) if want_S else None)
+    if rc:
+        raise RuntimeError(f"orc_sgm failed: {rc}")
+    return (disp, S) if want_S else disp
+
+
+def lr_check(dL, dR, thresh=1.0):
+    dL = np.ascontiguousarray(dL, np.float32)
+    dR = np.ascontiguousarray(dR, np.float32)
+    H, W = dL.shape
+    vl = np.empty((H, W), np.uint8)
+    vr = np.empty((H, W), np.uint8)
+    lib().orc_lr_check(_p(dL), _p(dR), H, W, C.c_float(thresh), _p(vl), _p(vr))
+    return vl, vr
+
+
+def init_undistort_rectify_map(K, dist, R, P, size):
+    W, H = size
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    P = np.ascontiguousarray(P, np.float64)
+    if P.size == 9:
+        P = np.hstack([P.reshape(3, 3), np.zeros((3, 1))])
+    P = np.ascontiguousarray(P.reshape(12))
+    dist = np.ascontiguousarray(dist, np.float64).reshape(-1)
+    m1 = np.empty((H, W, 2), np.int16)
+    m2 = np.empty((H, W), np.uint16)
+    lib().orc_init_undistort_rectify_map(_p(K), _p(dist), dist.size, _p(R), _p(P), W, H, _p(m1), _p(m2))
+    return m1, m2
+
+
+def remap(src, map1, map2):
+    src = _u8(src)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    m1 = np.ascontiguousarray(map1, np.int16)
+    m2 = np.ascontiguousarray(map2, np.uint16)
+    dH, dW = m2.shape
+    dst = np.empty((dH, dW) + ((cn,) if src.ndim == 3 else ()), np.uint8)
+    lib().orc_remap_bilinear_u8(_p(src), src.shape[0], src.shape[1], cn, _p(m1), _p(m2), dH, dW, _p(dst))
+    return dst
