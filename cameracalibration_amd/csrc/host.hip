@@ -87,7 +87,8 @@ static inline int reflect_i(int p, int n)
 
 // Synthetic rectified pair: right = xorshift32(seed) white noise low-passed by a 5x5 integer box
 // (texture with local structure); ground-truth disparity = piecewise-planar sawtooth
-// d(x,y) = clamp(round(D/4 + D/2 * frac(x/64 + y/48)), 0, D-1); left(x,y) = right(reflect(x - d), y)
+// d(x,y) = clamp(round(D/4 + D/2 * frac(x/(4D) + y/(3D))), 0, D-1) (disparity gradient 1/8 px per px
+// inside a plane, a D/2 jump between planes); left(x,y) = right(reflect(x - d), y)
 // plus i.i.d. noise in [-2, 2] from xorshift32(seed + 1).
 extern "C" int mdisp_synth_pair(uint32_t seed, int rows, int cols, int numDisp, uint8_t* left, uint8_t* right, uint16_t* gt)
 {
@@ -112,7 +113,7 @@ extern "C" int mdisp_synth_pair(uint32_t seed, int rows, int cols, int numDisp, 
     uint32_t s2 = (seed ? seed : 0x5EED0001u) + 1;
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
-            double t = x / 64.0 + y / 48.0;
+            double t = x / (4.0 * numDisp) + y / (3.0 * numDisp);
             t -= floor(t);
             int d = (int)lrint(numDisp / 4.0 + (numDisp / 2.0) * t);
             if (d < 0) d = 0;
