@@ -232,12 +232,12 @@ static int check_pair(const mdisp_image* L, const mdisp_image* R, const mdisp_pa
 struct PairBufs {
     u8 *ref, *other, *pad, *cRef, *cPad, *scr, *stage;
     size_t pitchW, pitchP, pitch3;
-    void* out; int* I; int* best;
+    void* out; int* I; int* best; void* extra;
 };
 
 // lay out and upload a pair; `ref` is the view the disparity is computed for
 static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p,
-                      size_t out_bytes, bool need_sat, PairBufs* b)
+                      size_t out_bytes, bool need_sat, PairBufs* b, size_t extra_bytes = 0)
 {
     const int H = L->rows, W = L->cols, Wp = W + p->maxDisparity;
     b->pitchW = md_align(W, 256); b->pitchP = md_align(Wp, 256); b->pitch3 = md_align((size_t)W * 3, 256);
@@ -247,11 +247,13 @@ static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     size_t o_st = cv.take(b->pitch3 * H), o_out = cv.take(out_bytes);
     size_t o_I = 0, o_best = 0;
     if (need_sat) { o_I = cv.take((size_t)(H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 4); }
+    size_t o_extra = cv.take(extra_bytes);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     b->ref = base + o_ref; b->other = base + o_oth; b->pad = base + o_pad; b->cRef = base + o_cr; b->cPad = base + o_cp;
     b->scr = base + o_scr; b->stage = base + o_st; b->out = base + o_out;
     b->I = (int*)(base + o_I); b->best = (int*)(base + o_best);
+    b->extra = base + o_extra;
     int rc;
     const mdisp_image* refIm = p->isDispLeft ? L : R;
     const mdisp_image* othIm = p->isDispLeft ? R : L;
@@ -263,13 +265,12 @@ static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
 // Device-side body shared by the host and _dev census-stereo entry points.
 static int census_stereo_body(mdisp_ctx* c, const u8* ref, const u8* other, size_t pitch, int H, int W,
                               const mdisp_param* p, int method, int agg, u8* pad, size_t pitchP, u8* cRef, size_t pitchC,
-                              u8* cPad, u8* scr, double* dOut)
+                              u8* cPad, u8* scr, double* dOut, void* gifScratch)
 {
     const int maxD = p->maxDisparity, minD = p->minDisparity, Wp = W + maxD;
     int rc;
     hipStream_t s = c->stream;
-    MD_REQUIRE(agg == MDISP_AGG_NONE || agg == MDISP_AGG_BOX || agg == MDISP_AGG_SQRBOX, MDISP_E_UNSUPPORTED,
-               "aggregation mode %d is not built yet", agg);
+    MD_REQUIRE(agg >= MDISP_AGG_NONE && agg <= MDISP_AGG_GUIDED, MDISP_E_BADARG, "unknown aggregation mode %d", agg);
     // left-disparity branch pads the right image on the left (:862), right-disparity branch pads
     // the left image on the right (:1005); both BORDER_REFLECT
     if (p->isDispLeft) rc = md_pad_reflect_lr(s, other, pitch, H, W, maxD, 0, pad, pitchP);
@@ -279,6 +280,14 @@ static int census_stereo_body(mdisp_ctx* c, const u8* ref, const u8* other, size
     if ((rc = md_census(s, ref, pitch, H, W, method, arg, cRef, pitchC, scr))) return rc;
     if ((rc = md_census(s, pad, pitchP, H, Wp, method, arg, cPad, pitchP, scr))) return rc;
     const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
+    if (agg == MDISP_AGG_GUIDED) {
+        // getGuidedFilter(img, slice, winSize, 1e-6) per slice (:978, :1120).  The left-disparity
+        // branch narrows the slice to CV_8U first (normalised in float), the right-disparity
+        // branch passes CV_32S (normalised in double).
+        return md_gif_stereo(c, gifScratch, ref, pitch, H, W, maxD - minD + 1, minD, p->winSize, 1e-6, MDISP_GIF, 0, 0.0,
+                             cRef, pitchC, cPad, pitchP, off0, offStep, MD_COST_HAMMING, nullptr, p->isDispLeft ? 0 : 1,
+                             nullptr, dOut);
+    }
     const int win = agg == MDISP_AGG_NONE ? 1 : p->winSize;
     const int kind = agg == MDISP_AGG_SQRBOX ? MD_COST_HAMMING_SQR : MD_COST_HAMMING;
     return md_cost_box_wta(s, cRef, pitchC, cPad, pitchP, H, W, minD, maxD, off0, offStep, win, kind, MD_OUT_F64, dOut, W);
@@ -294,10 +303,11 @@ extern "C" int mdisp_census_stereo(mdisp_ctx* c, const mdisp_image* L, const mdi
     MD_HIP(hipSetDevice(c->device));
     const int H = L->rows, W = L->cols;
     PairBufs b;
-    if ((rc = stage_pair(c, L, R, p, (size_t)H * W * 8, false, &b))) return rc;
+    const size_t extra = agg_mode == MDISP_AGG_GUIDED ? md_gif_scratch_bytes(H, W, p->maxDisparity - p->minDisparity + 1) : 0;
+    if ((rc = stage_pair(c, L, R, p, (size_t)H * W * 8, false, &b, extra))) return rc;
     // census rows are read as dwords: the census of `ref` uses the padded-width pitch as well
     if ((rc = census_stereo_body(c, b.ref, b.other, b.pitchW, H, W, p, census_method, agg_mode, b.pad, b.pitchP, b.cRef,
-                                 b.pitchP, b.cPad, b.scr, (double*)b.out))) return rc;
+                                 b.pitchP, b.cPad, b.scr, (double*)b.out, b.extra))) return rc;
     MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, (size_t)W * 8, (size_t)W * 8, H, hipMemcpyDeviceToHost, c->stream));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
@@ -316,12 +326,13 @@ extern "C" int mdisp_census_stereo_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     const size_t pitchP = md_align(Wp, 256);
     Carver cv;
     size_t o_pad = cv.take(pitchP * rows), o_cr = cv.take(pitchP * rows), o_cp = cv.take(pitchP * rows), o_scr = cv.take(pitchP * rows);
+    size_t o_gif = cv.take(agg_mode == MDISP_AGG_GUIDED ? md_gif_scratch_bytes(rows, cols, p->maxDisparity - p->minDisparity + 1) : 0);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     const u8* ref = p->isDispLeft ? d_left : d_right;
     const u8* other = p->isDispLeft ? d_right : d_left;
     return census_stereo_body(c, ref, other, pitch, rows, cols, p, census_method, agg_mode, base + o_pad, pitchP,
-                              base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp);
+                              base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp, base + o_gif);
 }
 
 static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out, bool inte)
@@ -355,6 +366,43 @@ extern "C" int mdisp_sad_inte(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
 
 extern "C" int mdisp_sad_box(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out)
 { return sad_common(c, L, R, p, out, false); }
+
+extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, double eps,
+                              int gif_type, int r2, double namda, double h, int cost_source, const float* costs, mdisp_image* out)
+{
+    (void)h;   // accepted and unused, as in the reference's filters
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_pair(L, R, p))) return rc;
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_32F, 1, "out"))) return rc;
+    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_SKWGIF, MDISP_E_UNSUPPORTED,
+               "GIF type %d is not built (OURS_GIF* need the bilateral stage)", gif_type);
+    MD_REQUIRE(cost_source != MDISP_COST_VOLUME || costs, MDISP_E_BADARG, "cost volume source needs the slices");
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols, maxD = p->maxDisparity, minD = p->minDisparity, D = maxD - minD + 1, Wp = W + maxD;
+    PairBufs b;
+    if ((rc = stage_pair(c, L, R, p, (size_t)H * W * 4, false, &b, md_gif_scratch_bytes(H, W, D)))) return rc;
+    hipStream_t s = c->stream;
+    const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
+    const u8 *cr = nullptr, *cp = nullptr; size_t crp = 0, cpp = 0; int kind = -1;
+    if (cost_source != MDISP_COST_VOLUME) {
+        if (p->isDispLeft) rc = md_pad_reflect_lr(s, b.other, b.pitchW, H, W, maxD, 0, b.pad, b.pitchP);
+        else rc = md_pad_reflect_lr(s, b.other, b.pitchW, H, W, 0, maxD, b.pad, b.pitchP);
+        if (rc) return rc;
+        if (cost_source == MDISP_COST_CENSUS) {
+            if ((rc = md_census(s, b.ref, b.pitchW, H, W, MDISP_BASIC_CENSUS, 0, b.cRef, b.pitchP, b.scr))) return rc;
+            if ((rc = md_census(s, b.pad, b.pitchP, H, Wp, MDISP_BASIC_CENSUS, 0, b.cPad, b.pitchP, b.scr))) return rc;
+            cr = b.cRef; crp = b.pitchP; cp = b.cPad; cpp = b.pitchP; kind = MD_COST_HAMMING;
+        } else if (cost_source == MDISP_COST_ABSDIFF) {
+            cr = b.ref; crp = b.pitchW; cp = b.pad; cpp = b.pitchP; kind = MD_COST_ABSDIFF;
+        } else { mdisp_set_error("unknown cost source %d", cost_source); return MDISP_E_BADARG; }
+    }
+    if ((rc = md_gif_stereo(c, b.extra, b.ref, b.pitchW, H, W, D, minD, p->winSize, eps, gif_type, r2, namda, cr, crp, cp, cpp,
+                            off0, offStep, kind, cost_source == MDISP_COST_VOLUME ? costs : nullptr, 0, (float*)b.out, nullptr))) return rc;
+    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // SGM

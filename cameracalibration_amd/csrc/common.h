@@ -75,6 +75,12 @@ int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, f
 int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
              int dH, int dW, u8* dst, size_t dp);
 
+// filters.hip: guided-filter aggregation of D cost slices + first-minimum WTA
+size_t md_gif_scratch_bytes(int H, int W, int D);
+int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
+                  int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
+                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64);
+
 // cost kinds of md_cost_box_wta
 enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };
 // output kinds

@@ -1,13 +1,786 @@
-// Guided-image-filter family and steerable-filter weights (placeholder until the kernels land).
+// Guided-image-filter family used as cost-slice aggregator, the steerable-filter weight map, and
+// the asw_gifs / censusStereo(GUIDED) drivers, for gfx950.
+//
+// Replaces cameraCalibration/disp_method/gifs.cpp:47-135 (getGuidedFilter), :227-273 (_egif),
+// :347-409 (edgeAwareWeight, _wgif), :537-617 (_skwgif2), disp_method/steerFilter.cpp:239-446
+// (steerFilter) and the per-slice loop + WTA of disp_method/methods_disp.cpp:1181-1215,1278-1295
+// and :969-1000.
+//
+// Numerics follow the reference's rounding points: images are float, every cv::Mat expression
+// rounds to float per operation (no fused multiply-add), cv::boxFilter accumulates in double and
+// rounds the scaled sum to float.  Slices are processed in batches of planar [n][H][W] arrays; all
+// guide-only terms (means, variance, regularisation map, steer weights) are computed once per
+// guide image, not once per disparity.
 #include "common.h"
+#include <math.h>
+#include <float.h>
+#include <vector>
 
-extern "C" int mdisp_guided_filter(mdisp_ctx*, const mdisp_image*, const mdisp_image*, int, double, int,
-                                   const mdisp_image*, int, double, mdisp_image*, mdisp_image*)
-{ mdisp_set_error("guided filter kernels are not built yet"); return MDISP_E_UNSUPPORTED; }
+__device__ __forceinline__ int r101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - p - 2;
+    return p;
+}
 
-extern "C" int mdisp_steer_filter(mdisp_ctx*, const mdisp_image*, mdisp_image*)
-{ mdisp_set_error("steer filter kernel is not built yet"); return MDISP_E_UNSUPPORTED; }
+// ---------------------------------------------------------------------------------------------
+// min / max and normalisation (cv::normalize(src, dst, 0, 1, NORM_MINMAX, CV_32F))
 
-extern "C" int mdisp_asw_gifs(mdisp_ctx*, const mdisp_image*, const mdisp_image*, const mdisp_param*, double, int, int,
-                              double, double, int, const float*, mdisp_image*)
-{ mdisp_set_error("asw_gifs is not built yet"); return MDISP_E_UNSUPPORTED; }
+// order-preserving map float -> uint32 so atomicMin/Max work on floats of either sign
+__device__ __forceinline__ u32 f2ord(float f) { u32 u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(u32 o) { u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; return __uint_as_float(u); }
+
+// mm[2*k] = min, mm[2*k+1] = max, both in the ordered-uint domain; init to (0xFFFFFFFF, 0)
+__global__ void mm_init_kernel(u32* mm, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+
+__device__ __forceinline__ void block_minmax_commit(u32 lo, u32 hi, u32* mm)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, (u32)__shfl_xor((int)lo, m, 64));
+        hi = max(hi, (u32)__shfl_xor((int)hi, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void minmax_kernel(const T* __restrict__ src, size_t n_per_slice, u32* mm)
+{
+    const int k = blockIdx.y;
+    const T* s = src + (size_t)k * n_per_slice;
+    u32 lo = 0xFFFFFFFFu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_per_slice; i += (size_t)gridDim.x * 256) {
+        u32 o = f2ord((float)s[i]);
+        lo = min(lo, o); hi = max(hi, o);
+    }
+    block_minmax_commit(lo, hi, mm + 2 * k);
+}
+
+struct CostSrc {
+    const u8* ref; size_t rp; const u8* pad; size_t pp;
+    int W, H, off0, offStep, kind;   // kind: MD_COST_HAMMING or MD_COST_ABSDIFF
+};
+__device__ __forceinline__ int raw_cost(const CostSrc& c, int x, int y, int k)
+{
+    const int r = c.ref[(size_t)y * c.rp + x], p = c.pad[(size_t)y * c.pp + x + c.off0 + k * c.offStep];
+    if (c.kind == MD_COST_HAMMING) return __popc((u32)(r ^ p));
+    return r > p ? r - p : p - r;
+}
+
+// min/max of integer cost slices k0 .. k0+n-1 computed on the fly
+__global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, u32* mm)
+{
+    const int k = blockIdx.y;
+    u32 lo = 0xFFFFFFFFu, hi = 0u;
+    const size_t N = (size_t)c.W * c.H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / c.W), x = (int)(i - (size_t)y * c.W);
+        u32 o = f2ord((float)raw_cost(c, x, y, k0 + k));
+        lo = min(lo, o); hi = max(hi, o);
+    }
+    block_minmax_commit(lo, hi, mm + 2 * k);
+}
+
+// convertTo(dst, CV_32F, scale, shift): float arithmetic for 8U / 32F sources, double for 32S
+enum { NORM_FLOAT = 0, NORM_DOUBLE = 1 };
+__device__ __forceinline__ float norm_apply(float v, u32 olo, u32 ohi, int mode)
+{
+    const double smin = (double)ord2f(olo), smax = (double)ord2f(ohi);
+    const double scale = (smax - smin > DBL_EPSILON) ? 1.0 / (smax - smin) : 0.0;
+    const double shift = 0.0 - smin * scale;
+    if (mode == NORM_DOUBLE) return (float)((double)v * scale + shift);
+    return __fadd_rn(__fmul_rn(v, (float)scale), (float)shift);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_kernel(const T* __restrict__ src, size_t n_per_slice, const u32* mm, int mode,
+                                                        float* __restrict__ dst)
+{
+    const int k = blockIdx.y;
+    const u32 lo = mm[2 * k], hi = mm[2 * k + 1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_per_slice; i += (size_t)gridDim.x * 256)
+        dst[(size_t)k * n_per_slice + i] = norm_apply((float)src[(size_t)k * n_per_slice + i], lo, hi, mode);
+}
+
+// strided 8-bit image -> planar normalised float
+__global__ __launch_bounds__(256) void normalize_u8_image_kernel(const u8* __restrict__ src, size_t sp, int H, int W, const u32* mm,
+                                                                 float* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    dst[(size_t)y * W + x] = norm_apply((float)src[(size_t)y * sp + x], mm[0], mm[1], NORM_FLOAT);
+}
+__global__ __launch_bounds__(256) void minmax_u8_image_kernel(const u8* __restrict__ src, size_t sp, int H, int W, u32* mm)
+{
+    u32 lo = 0xFFFFFFFFu, hi = 0u;
+    for (int y = blockIdx.y; y < H; y += gridDim.y)
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
+            u32 o = f2ord((float)src[(size_t)y * sp + x]);
+            lo = min(lo, o); hi = max(hi, o);
+        }
+    block_minmax_commit(lo, hi, mm);
+}
+
+__global__ __launch_bounds__(256) void cost_normalize_kernel(CostSrc c, int k0, const u32* mm, int mode, float* __restrict__ dst)
+{
+    const int k = blockIdx.y;
+    const u32 lo = mm[2 * k], hi = mm[2 * k + 1];
+    const size_t N = (size_t)c.W * c.H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / c.W), x = (int)(i - (size_t)y * c.W);
+        dst[(size_t)k * N + i] = norm_apply((float)raw_cost(c, x, y, k0 + k), lo, hi, mode);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// separable box sums with double accumulators (cv::boxFilter's RowSum<float,double> /
+// ColumnSum<double,float>).  mode 0: centred window k with BORDER_REFLECT_101.  mode 1: the
+// clipped half-open window of getGuidedFilter_skwgif2, [p - k/2, p + k/2) intersected with
+// [0, n-1)  (gifs.cpp:591-592: Rect(Point(max(0,i-r2/2), ...), Point(min(W-1,i+r2/2), ...))).
+
+#define BH_SEG 1024   // outputs per workgroup along x
+// out[k][y][x] = sum over the window of A[k][y][.] (times B[.][y][.], rounded to float first, when B != null)
+__global__ __launch_bounds__(256) void box_h_kernel(const float* __restrict__ A, size_t aStride, const float* __restrict__ B,
+                                                    size_t bStride, int H, int W, int ksz, int mode, double* __restrict__ out)
+{
+    extern __shared__ float seg[];   // BH_SEG + ksz values
+    const int y = blockIdx.y, k = blockIdx.z, x0 = blockIdx.x * BH_SEG;
+    const int ax = ksz / 2;
+    const float* a = A + (size_t)k * aStride + (size_t)y * W;
+    const float* b = B ? B + (size_t)k * bStride + (size_t)y * W : nullptr;
+    const int nload = min(BH_SEG, W - x0) + ksz;
+    for (int i = threadIdx.x; i < nload; i += 256) {
+        int xs = x0 - ax + i;
+        float v = 0.f;
+        if (mode == 0) { xs = r101(xs, W); v = b ? __fmul_rn(a[xs], b[xs]) : a[xs]; }
+        else if (xs >= 0 && xs < W - 1) v = b ? __fmul_rn(a[xs], b[xs]) : a[xs];
+        seg[i] = v;
+    }
+    __syncthreads();
+    // mode 1 window is [x-ax, x+ax): ksz-1 (even) or ksz (odd ksz: 2*ax = ksz-1) taps
+    const int taps = mode == 0 ? ksz : 2 * ax;
+    const int xb = threadIdx.x * 4;
+    if (x0 + xb >= W) return;
+    double s = 0;
+    for (int i = 0; i < taps; i++) s += (double)seg[xb + i];
+    double* o = out + ((size_t)k * H + y) * W + x0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (x0 + xb + j >= W) break;
+        if (j > 0) s += (double)seg[xb + j - 1 + taps] - (double)seg[xb + j - 1];
+        o[xb + j] = s;
+    }
+}
+
+#define BV_SEG 16   // outputs per thread along y
+// out[k][y][x] = (float)(sum over the window of in[k][.][x] * scale)            (div == null)
+//              = (float)(sum / div[y][x])                                        (div != null)
+__global__ __launch_bounds__(256) void box_v_kernel(const double* __restrict__ in, int H, int W, int ksz, int mode, double scale,
+                                                    const double* __restrict__ div, float* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, k = blockIdx.z, y0 = blockIdx.y * BV_SEG;
+    if (x >= W) return;
+    const int ay = ksz / 2;
+    const int taps = mode == 0 ? ksz : 2 * ay;
+    const double* col = in + (size_t)k * H * W + x;
+    auto tap = [&](int yy) -> double {
+        if (mode == 0) return col[(size_t)r101(yy, H) * W];
+        return (yy >= 0 && yy < H - 1) ? col[(size_t)yy * W] : 0.0;
+    };
+    double s = 0;
+    for (int i = 0; i < taps; i++) s += tap(y0 - ay + i);
+    for (int j = 0; j < BV_SEG; j++) {
+        const int y = y0 + j;
+        if (y >= H) break;
+        if (j > 0) s += tap(y - 1 - ay + taps) - tap(y - 1 - ay);
+        const size_t o = ((size_t)k * H + y) * W + x;
+        out[o] = div ? (float)(s * 1.0 / div[(size_t)y * W + x]) : (float)(s * scale);
+    }
+}
+
+// same vertical pass but keeping the double sum (used for the steer-weight normaliser)
+__global__ __launch_bounds__(256) void box_v_f64_kernel(const double* __restrict__ in, int H, int W, int ksz, int mode,
+                                                        double* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * BV_SEG;
+    if (x >= W) return;
+    const int ay = ksz / 2;
+    const int taps = mode == 0 ? ksz : 2 * ay;
+    const double* col = in + x;
+    auto tap = [&](int yy) -> double {
+        if (mode == 0) return col[(size_t)r101(yy, H) * W];
+        return (yy >= 0 && yy < H - 1) ? col[(size_t)yy * W] : 0.0;
+    };
+    double s = 0;
+    for (int i = 0; i < taps; i++) s += tap(y0 - ay + i);
+    for (int j = 0; j < BV_SEG; j++) {
+        const int y = y0 + j;
+        if (y >= H) break;
+        if (j > 0) s += tap(y - 1 - ay + taps) - tap(y - 1 - ay);
+        out[(size_t)y * W + x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise stages
+
+// varG = corrG - meanG*meanG   (gifs.cpp:80)
+__global__ __launch_bounds__(256) void var_kernel(const float* __restrict__ corr, const float* __restrict__ mean, size_t N,
+                                                  float* __restrict__ var)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) var[i] = __fsub_rn(corr[i], __fmul_rn(mean[i], mean[i]));
+}
+
+// den = var + add              (GIF / EGIF: add is a scalar)
+__global__ __launch_bounds__(256) void den_scalar_kernel(const float* __restrict__ var, size_t N, float add, float* __restrict__ den)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) den[i] = __fadd_rn(var[i], add);
+}
+
+// SKWGIF: temp = var2 + namuda;  writes temp and 1/temp (for the global sum)   (gifs.cpp:564-565)
+__global__ __launch_bounds__(256) void skw_temp_kernel(const float* __restrict__ var2, size_t N, float namuda,
+                                                       float* __restrict__ temp, float* __restrict__ inv)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) { float t = __fadd_rn(var2[i], namuda); temp[i] = t; inv[i] = __fdiv_rn(1.0f, t); }
+}
+// den = var + eps / (temp * gscale)                                            (gifs.cpp:565,570)
+__global__ __launch_bounds__(256) void skw_den_kernel(const float* __restrict__ var, const float* __restrict__ temp, size_t N,
+                                                      float gscale, float epsf, float* __restrict__ den)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) den[i] = __fadd_rn(var[i], __fdiv_rn(epsf, __fmul_rn(temp[i], gscale)));
+}
+
+__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* __restrict__ a, size_t n, float* __restrict__ o)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = (float)a[i];
+}
+
+// per-block partial sums in double, combined on the host in block order (deterministic)
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ src, size_t N, double* __restrict__ part)
+{
+    __shared__ double sh[256];
+    double s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) s += (double)src[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// a = (corrGP - meanG*meanP) / den ;  b = meanP - a*meanG        (gifs.cpp:96,127-128)
+// in: meanP, corrGP (per slice), meanG, den (per guide);  out: a overwrites corrGP's slot, b meanP's
+__global__ __launch_bounds__(256) void ab_kernel(float* __restrict__ meanP_b, float* __restrict__ corr_a,
+                                                 const float* __restrict__ meanG, const float* __restrict__ den, size_t N)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const size_t o = (size_t)blockIdx.y * N + i;
+    const float mp = meanP_b[o], mg = meanG[i];
+    const float cov = __fsub_rn(corr_a[o], __fmul_rn(mg, mp));
+    const float a = __fdiv_rn(cov, den[i]);
+    corr_a[o] = a;
+    meanP_b[o] = __fsub_rn(mp, __fmul_rn(a, mg));
+}
+
+// w*a products for the steer-weighted mean are formed inside box_h (B = steer weights)
+
+// out = a_bar*G + b_bar (gifs.cpp:133); optional store of the filtered slice and of
+// beta = a_bar / (1 - a_bar) (gifs.cpp:261); optional first-minimum WTA over the n slices of the
+// batch against the running best (strict '<': methods_disp.cpp:1287, minMaxLoc at :996).
+struct OutArgs {
+    const float* abar; const float* bbar; const float* G; size_t N; int n;
+    float* filtered; float* beta;
+    float* best; float* disp32; double* disp64; int d0;   // d0 = disparity of the batch's first slice
+    int first;                                            // 1: the running best is uninitialised
+};
+__global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const float g = a.G[i];
+    float best = 0.f; int bestd = 0; bool have = false;
+    if (a.best && !a.first) { best = a.best[i]; have = true; bestd = a.disp32 ? (int)a.disp32[i] : (int)a.disp64[i]; }
+    for (int k = 0; k < a.n; k++) {
+        const size_t o = (size_t)k * a.N + i;
+        const float ab = a.abar[o];
+        const float v = __fadd_rn(__fmul_rn(ab, g), a.bbar[o]);
+        if (a.filtered) a.filtered[o] = v;
+        if (a.beta) a.beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
+        if (a.best) {
+            if (!have || v < best) { best = v; bestd = a.d0 + k; have = true; }
+        }
+    }
+    if (a.best) {
+        a.best[i] = best;
+        if (a.disp32) a.disp32[i] = (float)bestd;
+        if (a.disp64) a.disp64[i] = (double)bestd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// steerable-filter orientation strength (steerFilter.cpp:239-446)
+
+struct SteerTaps { double k[7][121]; };   // G2a, G2b, H2a, H2b, G2c, H2c, H2d sampled at integer taps
+
+__device__ __forceinline__ int reflect_b(int p, int n)   // BORDER_REFLECT
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p - 1 : 2 * n - p - 1;
+    return p;
+}
+
+#define ST_T 16
+// One thread per source pixel: seven 11x11 correlations over the 6-px reflect-padded image
+// (taps reach 5 px), the C2/C3 quadratic forms and sqrt(C2^2 + C3^2); the running maximum is kept
+// as an ordered-bits atomicMax (the values are non-negative doubles).
+__global__ __launch_bounds__(ST_T * ST_T) void steer_strength_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
+                                                                     const SteerTaps* __restrict__ taps,
+                                                                     double* __restrict__ O, unsigned long long* __restrict__ maxbits)
+{
+    __shared__ float tile[ST_T + 10][ST_T + 10];
+    __shared__ double kk[7][121];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int x0 = blockIdx.x * ST_T, y0 = blockIdx.y * ST_T;
+    for (int i = ty * ST_T + tx; i < 7 * 121; i += ST_T * ST_T) kk[i / 121][i % 121] = taps->k[i / 121][i % 121];
+    for (int i = ty * ST_T + tx; i < (ST_T + 10) * (ST_T + 10); i += ST_T * ST_T) {
+        const int ry = i / (ST_T + 10), rx = i % (ST_T + 10);
+        tile[ry][rx] = (float)src[(size_t)reflect_b(y0 + ry - 5, H) * sp + reflect_b(x0 + rx - 5, W)];
+    }
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
+    double v = 0.0;
+    if (x < W && y < H) {
+        double s[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 11; k++)
+            for (int j = 0; j < 11; j++) {
+                const double p = (double)tile[ty + k][tx + j];
+#pragma unroll
+                for (int f = 0; f < 7; f++) s[f] = __dadd_rn(s[f], __dmul_rn(kk[f][k * 11 + j], p));
+            }
+        const double g2a = s[0], g2b = s[1], h2a = s[2], h2b = s[3], g2c = s[4], h2c = s[5], h2d = s[6];
+        auto sq = [](double t) { return __dmul_rn(t, t); };
+        double C2 = __dmul_rn(0.5, __dsub_rn(sq(g2a), sq(g2c)));
+        C2 = __dadd_rn(C2, __dmul_rn(0.46875, __dsub_rn(sq(h2a), sq(h2d))));
+        C2 = __dadd_rn(C2, __dmul_rn(0.28125, __dsub_rn(sq(h2b), sq(h2c))));
+        C2 = __dadd_rn(C2, __dmul_rn(0.1875, __dsub_rn(__dmul_rn(h2a, h2c), __dmul_rn(h2b, h2d))));
+        double C3 = __dsub_rn(-__dmul_rn(g2a, g2b), __dmul_rn(g2b, g2c));
+        C3 = __dsub_rn(C3, __dmul_rn(0.9375, __dsub_rn(__dmul_rn(h2c, h2d), __dmul_rn(h2a, h2b))));
+        C3 = __dsub_rn(C3, __dmul_rn(__dmul_rn(1.6875, h2b), h2c));
+        C3 = __dsub_rn(C3, __dmul_rn(__dmul_rn(0.1875, h2a), h2d));
+        v = sqrt(__dadd_rn(sq(C2), sq(C3)));
+        O[(size_t)y * W + x] = v;
+    }
+    // block max -> one atomic
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned long long o = __shfl_xor(b, m, 64);
+        b = o > b ? o : b;
+    }
+    if (((ty * ST_T + tx) & 63) == 0) atomicMax(maxbits, b);
+}
+
+// dst = clamp(O / max * 255, 1e-6, 120) with the reference's comparison order (:412, :434-441)
+__global__ __launch_bounds__(256) void steer_scale_kernel(const double* __restrict__ O, size_t N, const unsigned long long* maxbits,
+                                                          double* __restrict__ dst, float* __restrict__ dstf)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double mx = __longlong_as_double((long long)*maxbits);
+    double v = __dmul_rn(__ddiv_rn(__dmul_rn(O[i], 1.0), mx), 255.0);
+    if (v > 120) v = 120;
+    if (v < 1e-6) v = 1e-6;
+    if (dst) dst[i] = v;
+    if (dstf) dstf[i] = (float)v;
+}
+
+static double G2a(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 0.9213 * ((2 * xs) - 1) * ys; }
+static double G2b(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 1.843 * x * y * ys; }
+static double H2a(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 0.9780 * (-2.254 * x + x * xs) * ys; }
+static double H2b(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 0.9780 * (-0.7515 + xs) * y * ys; }
+static double H2c(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 0.9780 * (-0.7515 + y * y) * x * ys; }
+static double G2c(int x, int y) { double xs = x * x, ys = y * y; xs = exp(-(xs + ys)); return 0.9213 * ((2 * ys) - 1) * xs; }
+static double H2d(int x, int y) { double xs = pow(x, 2), ys = pow(y, 2); xs = exp(-(xs + ys)); return 0.9780 * (-2.254 * y + y * ys) * xs; }
+
+// O, maxbits, tapsDev: device scratch (N doubles, 8 bytes, sizeof(SteerTaps)); dst / dstf may be null
+static int steer_run(hipStream_t s, const u8* src, size_t sp, int H, int W, double* O, unsigned long long* maxbits,
+                     SteerTaps* tapsDev, double* dst, float* dstf)
+{
+    static SteerTaps host;   // basis kernels, steerFilter.cpp:283-293 (filled once; read-only afterwards)
+    static bool filled = false;
+    if (!filled) {
+        for (int y = -5; y <= 5; y++)
+            for (int x = -5; x <= 5; x++) {
+                const int i = (y + 5) * 11 + (x + 5);
+                host.k[0][i] = G2a(x, y); host.k[1][i] = G2b(x, y); host.k[2][i] = H2a(x, y); host.k[3][i] = H2b(x, y);
+                host.k[4][i] = G2c(x, y); host.k[5][i] = H2c(x, y); host.k[6][i] = H2d(x, y);
+            }
+        filled = true;
+    }
+    MD_HIP(hipMemcpyAsync(tapsDev, &host, sizeof(SteerTaps), hipMemcpyHostToDevice, s));
+    MD_HIP(hipMemsetAsync(maxbits, 0, 8, s));
+    dim3 grid((W + ST_T - 1) / ST_T, (H + ST_T - 1) / ST_T), block(ST_T, ST_T);
+    steer_strength_kernel<<<grid, block, 0, s>>>(src, sp, H, W, tapsDev, O, maxbits);
+    const size_t N = (size_t)H * W;
+    steer_scale_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(O, N, maxbits, dst, dstf);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+static int box_f32(hipStream_t s, const float* A, size_t aStride, const float* B, size_t bStride, int n, int H, int W, int k,
+                   int mode, double* tmp, const double* div, float* out)
+{
+    dim3 gh((W + BH_SEG - 1) / BH_SEG, H, n);
+    box_h_kernel<<<gh, 256, (BH_SEG + k + 8) * sizeof(float), s>>>(A, aStride, B, bStride, H, W, k, mode, tmp);
+    dim3 gv((W + 255) / 256, (H + BV_SEG - 1) / BV_SEG, n);
+    box_v_kernel<<<gv, 256, 0, s>>>(tmp, H, W, k, mode, 1.0 / ((double)k * k), div, out);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+static int device_sum(mdisp_ctx* c, const float* src, size_t N, double* partDev, double* result)
+{
+    const int nb = 240;
+    partial_sum_kernel<<<nb, 256, 0, c->stream>>>(src, N, partDev);
+    MD_HIP(hipGetLastError());
+    std::vector<double> h(nb);
+    MD_HIP(hipMemcpyAsync(h.data(), partDev, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    double s = 0;
+    for (int i = 0; i < nb; i++) s += h[i];
+    *result = s;
+    return MDISP_OK;
+}
+
+// everything that depends on the guide image only
+struct GuideState {
+    int H, W, r, r2, type;
+    float* G;        // normalised guide
+    float* meanG;
+    float* den;      // var + regulariser
+    float* w;        // steer weights as float (SKWGIF)
+    double* wsum;    // clipped-window sum of w (SKWGIF)
+};
+
+struct GifScratch {   // device scratch sized for n slices
+    size_t N; int n;
+    float *F0, *F1, *F2;      // n*N each
+    double* T;                // n*N
+    float *g0, *g1, *g2;      // N each (guide-only temporaries)
+    double* gd;               // N
+    u32* mm;                  // 2*(n+1)
+    double* part;             // 256
+    unsigned long long* maxbits; SteerTaps* taps;
+};
+
+static size_t gif_scratch_bytes(size_t N, int n)
+{
+    return md_align(N * n * 4, 256) * 3 + md_align(N * n * 8, 256) + md_align(N * 4, 256) * 8 + md_align(N * 8, 256) * 3 +
+           md_align((size_t)(2 * (n + 1)) * 4, 256) + 4096 + md_align(sizeof(SteerTaps), 256) + 4096;
+}
+
+struct Carve2 { u8* p; template <typename T> T* take(size_t count) { T* r = (T*)p; p += md_align(count * sizeof(T), 256); return r; } };
+
+// gaussian of a constant image: getGaussianKernel(3, 2) applied separably in float
+static float gauss3_const(float c)
+{
+    double k[3], ks = 0;
+    for (int i = 0; i < 3; i++) { double x = i - 1; k[i] = exp(-(x * x) / (2 * 2.0 * 2.0)); ks += k[i]; }
+    float kf[3];
+    for (int i = 0; i < 3; i++) kf[i] = (float)(k[i] / ks);
+    volatile float s = 0;
+    for (int i = 0; i < 3; i++) { volatile float t = kf[i] * c; s = s + t; }
+    const float row = s;
+    s = 0;
+    for (int i = 0; i < 3; i++) { volatile float t = kf[i] * row; s = s + t; }
+    return s;
+}
+
+static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, int W, int r, int r2, int type, double eps,
+                         double namuda, const double* steerW_dev, GifScratch& sc, GuideState& gs, Carve2& cv)
+{
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)H * W;
+    gs.H = H; gs.W = W; gs.r = r; gs.r2 = r2; gs.type = type;
+    gs.G = cv.take<float>(N); gs.meanG = cv.take<float>(N); gs.den = cv.take<float>(N);
+    gs.w = nullptr; gs.wsum = nullptr;
+    u32* mm = sc.mm;
+    mm_init_kernel<<<1, 64, 0, s>>>(mm, 1);
+    minmax_u8_image_kernel<<<dim3(4, 64), 256, 0, s>>>(dGuide, gpitch, H, W, mm);
+    normalize_u8_image_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(dGuide, gpitch, H, W, mm, gs.G);
+    int rc;
+    // meanG, corrG -> var (gifs.cpp:58-59,76-80)
+    if ((rc = box_f32(s, gs.G, 0, nullptr, 0, 1, H, W, r, 0, sc.gd, nullptr, gs.meanG))) return rc;
+    if ((rc = box_f32(s, gs.G, 0, gs.G, 0, 1, H, W, r, 0, sc.gd, nullptr, sc.g0))) return rc;
+    var_kernel<<<nblk(N), 256, 0, s>>>(sc.g0, gs.meanG, N, sc.g1);   // g1 = varG
+    const float epsf = (float)eps;
+    if (type == MDISP_GIF) {
+        den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, epsf, gs.den);
+    } else if (type == MDISP_EGIF) {
+        double sum;
+        if ((rc = device_sum(c, sc.g1, N, sc.part, &sum))) return rc;
+        const double mean2Var = sum / ((double)W * H);            // gifs.cpp:252
+        den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, (float)(mean2Var * eps + 0.001 * 0.001), gs.den);
+    } else if (type == MDISP_WGIF) {
+        // edgeAwareWeight (gifs.cpp:347-374): with r = 1 the box "variance" G*G - G*G is exactly 0,
+        // so gamma is one constant, evaluated here with the same float operations
+        u32 hmm[2];
+        MD_HIP(hipMemcpyAsync(hmm, mm, 8, hipMemcpyDeviceToHost, s));
+        MD_HIP(hipStreamSynchronize(s));
+        auto ord2f_h = [](u32 o) { u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; memcpy(&f, &u, 4); return f; };
+        const double smin = ord2f_h(hmm[0]), smax = ord2f_h(hmm[1]);
+        const double scale = (smax - smin > DBL_EPSILON) ? 1.0 / (smax - smin) : 0.0, shift = 0.0 - smin * scale;
+        volatile float gmin = (float)smin * (float)scale; gmin = gmin + (float)shift;
+        volatile float gmax = (float)smax * (float)scale; gmax = gmax + (float)shift;
+        const double L = (double)gmax - (double)gmin;
+        const double epsw = (0.001 * L) * (0.001 * L);
+        volatile float varG1 = 0.0f + (float)epsw;
+        volatile float inv = 1.0f / varG1;
+        const double val_ = ((double)inv * (double)N) / ((double)W * H);
+        volatile float g0v = varG1 * (float)val_;
+        const float gamma = gauss3_const(g0v);
+        volatile float e = epsf / gamma;
+        den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, e, gs.den);
+    } else if (type == MDISP_SKWGIF) {
+        MD_REQUIRE(steerW_dev && r2 >= 2, MDISP_E_BADARG, "SKWGIF needs the steer-filter weights and r2 >= 2");
+        // var over the r2 window (gifs.cpp:547,555,562)
+        if ((rc = box_f32(s, gs.G, 0, nullptr, 0, 1, H, W, r2, 0, sc.gd, nullptr, sc.g2))) return rc;     // meanG2
+        if ((rc = box_f32(s, gs.G, 0, gs.G, 0, 1, H, W, r2, 0, sc.gd, nullptr, sc.g0))) return rc;        // corrG2
+        float* var2 = cv.take<float>(N); float* temp = cv.take<float>(N); float* inv = cv.take<float>(N);
+        var_kernel<<<nblk(N), 256, 0, s>>>(sc.g0, sc.g2, N, var2);
+        skw_temp_kernel<<<nblk(N), 256, 0, s>>>(var2, N, (float)namuda, temp, inv);
+        double sum;
+        if ((rc = device_sum(c, inv, N, sc.part, &sum))) return rc;
+        const float gscale = (float)(sum / ((double)H * W));
+        skw_den_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, temp, N, gscale, epsf, gs.den);
+        // steer weights: float copy (gifs.cpp:574-577) and their clipped-window sum (:600)
+        gs.w = cv.take<float>(N); gs.wsum = cv.take<double>(N);
+        f64_to_f32_kernel<<<nblk(N), 256, 0, s>>>(steerW_dev, N, gs.w);
+        dim3 gh((W + BH_SEG - 1) / BH_SEG, H, 1);
+        box_h_kernel<<<gh, 256, (BH_SEG + r2 + 8) * sizeof(float), s>>>(gs.w, 0, nullptr, 0, H, W, r2, 1, sc.gd);
+        dim3 gv((W + 255) / 256, (H + BV_SEG - 1) / BV_SEG, 1);
+        double* hs2 = cv.take<double>(N);
+        box_v_f64_kernel<<<gv, 256, 0, s>>>(sc.gd, H, W, r2, 1, hs2);
+        gs.wsum = hs2;
+    } else {
+        mdisp_set_error("unknown GIF type %d", type);
+        return MDISP_E_BADARG;
+    }
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// filter n normalised slices held in sc.F0; leaves a_bar in F1 and b_bar in F2
+static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, int n)
+{
+    hipStream_t s = c->stream;
+    const int H = gs.H, W = gs.W, r = gs.r;
+    const size_t N = (size_t)H * W;
+    int rc;
+    // meanP -> F1, corrGP -> F2   (gifs.cpp:60-61,71)
+    if ((rc = box_f32(s, sc.F0, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F1))) return rc;
+    if ((rc = box_f32(s, sc.F0, N, gs.G, 0, n, H, W, r, 0, sc.T, nullptr, sc.F2))) return rc;
+    // a -> F2, b -> F1
+    ab_kernel<<<dim3(nblk(N), n), 256, 0, s>>>(sc.F1, sc.F2, gs.meanG, gs.den, N);
+    if (gs.type == MDISP_SKWGIF) {
+        // steer-weighted means: boxsum(w*a)/boxsum(w) over the clipped window (gifs.cpp:587-611)
+        if ((rc = box_f32(s, sc.F2, N, gs.w, 0, n, H, W, gs.r2, 1, sc.T, gs.wsum, sc.F0))) return rc;   // a_bar -> F0
+        if ((rc = box_f32(s, sc.F1, N, gs.w, 0, n, H, W, gs.r2, 1, sc.T, gs.wsum, sc.F2))) return rc;   // b_bar -> F2
+        float* t = sc.F1; sc.F1 = sc.F0; sc.F0 = t;   // a_bar now in F1
+    } else {
+        if ((rc = box_f32(s, sc.F2, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F0))) return rc;    // a_bar -> F0
+        if ((rc = box_f32(s, sc.F1, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F2))) return rc;    // b_bar -> F2
+        float* t = sc.F1; sc.F1 = sc.F0; sc.F0 = t;
+    }
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+static void scratch_carve(Carve2& cv, size_t N, int n, GifScratch& sc)
+{
+    sc.N = N; sc.n = n;
+    sc.F0 = cv.take<float>(N * n); sc.F1 = cv.take<float>(N * n); sc.F2 = cv.take<float>(N * n);
+    sc.T = cv.take<double>(N * n);
+    sc.g0 = cv.take<float>(N); sc.g1 = cv.take<float>(N); sc.g2 = cv.take<float>(N);
+    sc.gd = cv.take<double>(N);
+    sc.mm = cv.take<u32>(2 * (size_t)(n + 1));
+    sc.part = cv.take<double>(256);
+    sc.maxbits = cv.take<unsigned long long>(1);
+    sc.taps = cv.take<SteerTaps>(1);
+}
+
+static int pick_batch(size_t N, int D)
+{
+    size_t budget = (size_t)3 << 30;                 // bytes of per-slice scratch (20 B per pixel per slice)
+    size_t n = budget / (N * 20);
+    if (n < 1) n = 1;
+    if (n > (size_t)D) n = D;
+    return (int)n;
+}
+
+static size_t guide_extra_bytes(size_t N) { return md_align(N * 4, 256) * 8 + md_align(N * 8, 256) * 2; }
+
+static int check_img(const mdisp_image* im, const char* what)
+{
+    MD_REQUIRE(im && im->data && im->rows > 0 && im->cols > 0, MDISP_E_BADARG, "%s: empty image", what);
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_steer_filter(mdisp_ctx* c, const mdisp_image* src, mdisp_image* dst)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_img(src, "src")) || (rc = check_img(dst, "dst"))) return rc;
+    MD_REQUIRE(src->depth == MDISP_8U && src->channels == 1, MDISP_E_BADARG, "steerFilter needs a CV_8UC1 image");
+    MD_REQUIRE(dst->depth == MDISP_64F && dst->channels == 1 && dst->rows == src->rows && dst->cols == src->cols,
+               MDISP_E_BADARG, "dst must be CV_64FC1 of the source size");
+    MD_HIP(hipSetDevice(c->device));
+    const int H = src->rows, W = src->cols;
+    const size_t N = (size_t)H * W, pitch = md_align(W, 256);
+    size_t need = pitch * H + md_align(N * 8, 256) * 2 + md_align(sizeof(SteerTaps), 256) + 1024;
+    u8* base = (u8*)mdisp_ws(c, need);
+    if (!base) return MDISP_E_NOMEM;
+    Carve2 cv{base};
+    u8* dS = cv.take<u8>(pitch * H);
+    double* O = cv.take<double>(N); double* out = cv.take<double>(N);
+    SteerTaps* taps = cv.take<SteerTaps>(1);
+    unsigned long long* mb = cv.take<unsigned long long>(1);
+    hipStream_t s = c->stream;
+    MD_HIP(hipMemcpy2DAsync(dS, pitch, src->data, src->step_bytes, W, H, hipMemcpyHostToDevice, s));
+    if ((rc = steer_run(s, dS, pitch, H, W, O, mb, taps, out, nullptr))) return rc;
+    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, out, (size_t)W * 8, (size_t)W * 8, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_guided_filter(mdisp_ctx* c, const mdisp_image* guide, const mdisp_image* P, int r, double eps, int gif_type,
+                                   const mdisp_image* steerW, int r2, double namuda, mdisp_image* out, mdisp_image* beta)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_img(guide, "guidedImg")) || (rc = check_img(P, "inputP")) || (rc = check_img(out, "out"))) return rc;
+    MD_REQUIRE(guide->depth == MDISP_8U && guide->channels == 1, MDISP_E_UNSUPPORTED, "the guide must be CV_8UC1");
+    MD_REQUIRE(P->channels == 1 && P->rows == guide->rows && P->cols == guide->cols, MDISP_E_BADARG, "guide / input size mismatch");
+    MD_REQUIRE(P->depth == MDISP_8U || P->depth == MDISP_32S || P->depth == MDISP_32F, MDISP_E_UNSUPPORTED, "inputP must be 8U, 32S or 32F");
+    MD_REQUIRE(out->depth == MDISP_32F && out->rows == guide->rows && out->cols == guide->cols && out->channels == 1, MDISP_E_BADARG,
+               "out must be CV_32FC1 of the guide size");
+    MD_REQUIRE(r >= 1, MDISP_E_BADARG, "window must be >= 1");
+    if (beta) MD_REQUIRE(beta->depth == MDISP_32F && beta->rows == guide->rows && beta->cols == guide->cols, MDISP_E_BADARG, "bad beta image");
+    if (gif_type == MDISP_SKWGIF)
+        MD_REQUIRE(steerW && steerW->data && steerW->depth == MDISP_64F && steerW->rows == guide->rows && steerW->cols == guide->cols,
+                   MDISP_E_BADARG, "SKWGIF needs a CV_64F steer map of the guide size");
+    MD_HIP(hipSetDevice(c->device));
+    const int H = guide->rows, W = guide->cols;
+    const size_t N = (size_t)H * W, pitch = md_align(W, 256);
+    size_t need = gif_scratch_bytes(N, 1) + guide_extra_bytes(N) + pitch * H + md_align(N * 8, 256) * 2 + md_align(N * 4, 256) * 3 + 4096;
+    u8* base = (u8*)mdisp_ws(c, need);
+    if (!base) return MDISP_E_NOMEM;
+    Carve2 cv{base};
+    GifScratch sc; scratch_carve(cv, N, 1, sc);
+    u8* dG = cv.take<u8>(pitch * H);
+    double* dSteer = cv.take<double>(N);
+    u8* rawP = (u8*)cv.take<double>(N);      // raw input slice, any supported depth
+    float* dOut = cv.take<float>(N); float* dBeta = cv.take<float>(N);
+    hipStream_t s = c->stream;
+    MD_HIP(hipMemcpy2DAsync(dG, pitch, guide->data, guide->step_bytes, W, H, hipMemcpyHostToDevice, s));
+    if (gif_type == MDISP_SKWGIF)
+        MD_HIP(hipMemcpy2DAsync(dSteer, (size_t)W * 8, steerW->data, steerW->step_bytes, (size_t)W * 8, H, hipMemcpyHostToDevice, s));
+    const size_t esz = P->depth == MDISP_8U ? 1 : 4;
+    MD_HIP(hipMemcpy2DAsync(rawP, (size_t)W * esz, P->data, P->step_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, s));
+    GuideState gs;
+    if ((rc = guide_prepare(c, dG, pitch, H, W, r, r2, gif_type, eps, namuda, dSteer, sc, gs, cv))) return rc;
+    // normalise the slice (gifs.cpp:56)
+    u32* mm = sc.mm + 2;
+    mm_init_kernel<<<1, 64, 0, s>>>(mm, 1);
+    dim3 g1(240, 1);
+    if (P->depth == MDISP_8U) {
+        minmax_kernel<u8><<<g1, 256, 0, s>>>(rawP, N, mm);
+        normalize_kernel<u8><<<g1, 256, 0, s>>>(rawP, N, mm, NORM_FLOAT, sc.F0);
+    } else if (P->depth == MDISP_32S) {
+        minmax_kernel<int><<<g1, 256, 0, s>>>((const int*)rawP, N, mm);
+        normalize_kernel<int><<<g1, 256, 0, s>>>((const int*)rawP, N, mm, NORM_DOUBLE, sc.F0);
+    } else {
+        minmax_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm);
+        normalize_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm, NORM_FLOAT, sc.F0);
+    }
+    if ((rc = gif_filter_batch(c, gs, sc, 1))) return rc;
+    OutArgs oa;
+    oa.abar = sc.F1; oa.bbar = sc.F2; oa.G = gs.G; oa.N = N; oa.n = 1; oa.filtered = dOut; oa.beta = beta ? dBeta : nullptr;
+    oa.best = nullptr; oa.disp32 = nullptr; oa.disp64 = nullptr; oa.d0 = 0; oa.first = 1;
+    out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, dOut, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
+    if (beta) MD_HIP(hipMemcpy2DAsync(beta->data, beta->step_bytes, dBeta, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
+
+// Shared driver: guide + cost slices (computed on the device or uploaded) -> filtered slices -> WTA.
+// normMode: how the raw slice is normalised (float for 8U / 32F data, double for 32S data).
+size_t md_gif_scratch_bytes(int H, int W, int D)
+{
+    const size_t N = (size_t)H * W;
+    const int n = pick_batch(N, D);
+    return gif_scratch_bytes(N, n) + guide_extra_bytes(N) + md_align(N * 8, 256) * 3 + md_align(N * 4, 256) * 2 + 16384;
+}
+
+int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
+                  int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
+                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64)
+{
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)H * W;
+    const int n = pick_batch(N, D);
+    Carve2 cv{(u8*)scratch};
+    GifScratch sc; scratch_carve(cv, N, n, sc);
+    float* best = cv.take<float>(N);
+    double* O = cv.take<double>(N); double* steerD = cv.take<double>(N);
+    int rc;
+    if (gif_type == MDISP_SKWGIF) {
+        // asw_gifs computes the weights from the gray guide once (methods_disp.cpp:1176-1180)
+        if ((rc = steer_run(s, dGuide, gpitch, H, W, O, sc.maxbits, sc.taps, steerD, nullptr))) return rc;
+    }
+    GuideState gs;
+    if ((rc = guide_prepare(c, dGuide, gpitch, H, W, r, r2, gif_type, eps, namuda, steerD, sc, gs, cv))) return rc;
+    CostSrc cs;
+    cs.ref = ref; cs.rp = rp; cs.pad = pad; cs.pp = pp; cs.W = W; cs.H = H; cs.off0 = off0; cs.offStep = offStep; cs.kind = costKind;
+    for (int k0 = 0; k0 < D; k0 += n) {
+        const int nb = D - k0 < n ? D - k0 : n;
+        mm_init_kernel<<<(nb + 63) / 64, 64, 0, s>>>(sc.mm + 2, nb);
+        dim3 g(120, nb);
+        if (hostCosts) {
+            // slices arrive as float (computeDisp_Feature output); staged through the double scratch
+            float* raw = (float*)sc.T;
+            MD_HIP(hipMemcpyAsync(raw, hostCosts + (size_t)k0 * N, (size_t)nb * N * 4, hipMemcpyHostToDevice, s));
+            minmax_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2);
+            normalize_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2, NORM_FLOAT, sc.F0);
+        } else {
+            cost_minmax_kernel<<<g, 256, 0, s>>>(cs, k0, sc.mm + 2);
+            cost_normalize_kernel<<<g, 256, 0, s>>>(cs, k0, sc.mm + 2, normMode, sc.F0);
+        }
+        if ((rc = gif_filter_batch(c, gs, sc, nb))) return rc;
+        OutArgs oa;
+        oa.abar = sc.F1; oa.bbar = sc.F2; oa.G = gs.G; oa.N = N; oa.n = nb; oa.filtered = nullptr; oa.beta = nullptr;
+        oa.best = best; oa.disp32 = dDisp32; oa.disp64 = dDisp64; oa.d0 = minD + k0; oa.first = k0 == 0;
+        out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
+        MD_HIP(hipGetLastError());
+    }
+    return MDISP_OK;
+}

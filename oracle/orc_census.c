@@ -334,7 +334,14 @@ int orc_census_stereo(const uint8_t* L, const uint8_t* R, int H, int W, int winS
             for (long i = 0; i < N; i++) slice[i] = (float)u1[i];
             break;
         case ORC_AGG_GUIDED:
-            orc_normalize_minmax_s32(dist, N, pN);
+            /* the left-disparity branch narrows the slice to CV_8U first (:975) and so normalises
+             * in float; the right-disparity branch passes the CV_32S slice (:1120), which OpenCV
+             * normalises in double */
+            if (isDispLeft) {
+                uint8_t* d8 = (uint8_t*)u0;
+                for (long i = 0; i < N; i++) d8[i] = (uint8_t)dist[i];
+                orc_normalize_minmax_u8(d8, N, pN);
+            } else orc_normalize_minmax_s32(dist, N, pN);
             orc_guided_filter(guideN, pN, H, W, winSize, 1e-6, slice);
             break;
         default:

@@ -1,0 +1,119 @@
+"""GPU parity of the float paths (guided-filter family, steer filter, guided / asw aggregation)
+against the CPU oracle.  Tolerances: filtered slices max-abs <= 1e-3 on the [0,1]-normalised cost;
+float WTA may differ from the oracle only where the oracle's best-vs-runner-up gap is < 1e-5."""
+import numpy as np
+import pytest
+
+from conftest import rand_pair
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _textured(seed, H, W):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (H, W)).astype(np.float64)
+    from scipy import ndimage
+    a = ndimage.uniform_filter(a, 3, mode="mirror")
+    a = (a - a.min()) / (a.max() - a.min()) * 255
+    return a.astype(np.uint8)
+
+
+def _tie_aware_equal(got, exp, costs, minD, gap=1e-5):
+    """disparities equal, or the oracle's two best filtered costs are within `gap` there"""
+    bad = got != exp
+    if not bad.any():
+        return True
+    ys, xs = np.nonzero(bad)
+    for y, x in zip(ys, xs):
+        c = costs[:, y, x]
+        if abs(c[int(got[y, x]) - minD] - c[int(exp[y, x]) - minD]) >= gap:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("shape,r", [((48, 64), 7), ((37, 53), 5), ((90, 140), 15), ((60, 80), 35)])
+@pytest.mark.parametrize("dtype", [np.uint8, np.int32, np.float32])
+def test_guided_filter_gif(api, orc, shape, r, dtype):
+    guide = _textured(1, *shape)
+    rng = np.random.default_rng(2)
+    P = rng.integers(0, 9, shape).astype(dtype)
+    if dtype == np.float32:
+        P = P + rng.random(shape, dtype=np.float32)
+    for eps in (1e-2, 1e-6):
+        got = api.getGuidedFilter(guide, P, r, eps)
+        exp = orc.guided_filter(guide, P, r, eps, orc.GIF)
+        assert np.abs(got - exp).max() <= TOL
+
+
+@pytest.mark.parametrize("shape,r", [((48, 64), 7), ((37, 53), 9)])
+def test_guided_filter_wgif_egif(api, orc, shape, r):
+    guide = _textured(3, *shape)
+    rng = np.random.default_rng(4)
+    P = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = api.getGuidedFilter_wgif(guide, P, r, 0.01)
+    assert np.abs(got - orc.guided_filter(guide, P, r, 0.01, orc.WGIF)).max() <= TOL
+    got, beta = api.getGuidedFilter_egif(guide, P, r, 0.01)
+    exp, ebeta = orc.guided_filter(guide, P, r, 0.01, orc.EGIF, want_beta=True)
+    assert np.abs(got - exp).max() <= TOL
+    assert np.abs(beta - ebeta).max() <= TOL * max(1.0, np.abs(ebeta).max())
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (20, 150)])
+def test_steer_filter(api, orc, shape):
+    img = _textured(5, *shape)
+    got = api.steerFilter(img)
+    exp = orc.steer_filter(img)
+    assert got.dtype == np.float64
+    assert np.abs(got - exp).max() <= 1e-9 * 120
+
+
+@pytest.mark.parametrize("shape,r,r2", [((48, 64), 7, 5), ((40, 56), 9, 15)])
+def test_guided_filter_skwgif2(api, orc, shape, r, r2):
+    guide = _textured(6, *shape)
+    rng = np.random.default_rng(7)
+    P = rng.integers(0, 9, shape, dtype=np.uint8)
+    sw = orc.steer_filter(guide)
+    got = api.getGuidedFilter_skwgif2(guide, P, sw, r, r2, 0.01, 0.1)
+    exp = orc.guided_filter(guide, P, r, 0.01, orc.SKWGIF, steerW=sw, r2=r2, namuda=0.1)
+    assert np.abs(got - exp).max() <= TOL
+
+
+@pytest.mark.parametrize("left", [True, False])
+def test_census_stereo_guided_is_the_reference_default(api, orc, left):
+    L, R, _ = api.synth_pair(0x5EED0001, 96, 160, 32)
+    p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=7, minDisparity=0, maxDisparity=31, isDispLeft=left)
+    got = api.censusStereo(p, api.BASIC_CENSUS)          # agg defaults to AGG_GUIDED
+    exp, costs = orc.census_stereo(L, R, 7, 0, 31, left, orc.BASIC_CENSUS, orc.AGG_GUIDED, want_costs=True)
+    assert got.dtype == np.float64
+    assert (got == exp).mean() > 0.999
+    assert _tie_aware_equal(got, exp, costs, 0)
+
+
+@pytest.mark.parametrize("gif", [0, 1, 2, 3])
+@pytest.mark.parametrize("source", ["census", "absdiff", "volume"])
+def test_asw_gifs(api, orc, gif, source):
+    H, W, minD, maxD, win = 64, 96, 2, 17, 7
+    L, R, _ = api.synth_pair(0x5EED0003, H, W, 16)
+    D = maxD - minD + 1
+    pad = orc.pad_reflect_lr(R, maxD, 0)
+    if source == "census":
+        cL, cP = orc.census(L), orc.census(pad)
+        costs = np.stack([orc.hamming(cL, np.ascontiguousarray(cP[:, maxD - d:maxD - d + W])) for d in range(minD, maxD + 1)])
+        src = api.COST_CENSUS
+    else:
+        costs = np.stack([np.abs(L.astype(np.int32) - pad[:, maxD - d:maxD - d + W].astype(np.int32))
+                          for d in range(minD, maxD + 1)])
+        src = api.COST_ABSDIFF
+    costs = costs.astype(np.float32)
+    p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=win, minDisparity=minD, maxDisparity=maxD, isDispLeft=True)
+    if source == "volume":
+        got = api.asw_gifs(p, 0.01, gif, 5, 0.1, 0.5, api.COST_VOLUME, costs)
+    else:
+        got = api.asw_gifs(p, 0.01, gif, 5, 0.1, 0.5, src)
+    exp, filt = orc.asw_gifs(L, costs, minD, win, 0.01, gif, 5, 0.1, want_filtered=True)
+    assert got.dtype == np.float32 and got.shape == (H, W)
+    assert (got == exp).mean() > 0.999
+    assert _tie_aware_equal(got, exp, filt, minD)
+    assert D == filt.shape[0]
