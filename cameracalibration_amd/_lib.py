@@ -37,7 +37,7 @@ class mdisp_sgbm_params(C.Structure):
 EXPORTS = [
     "mdisp_version", "mdisp_last_error", "mdisp_device_count", "mdisp_create", "mdisp_destroy", "mdisp_synchronize",
     "mdisp_census_transform", "mdisp_hamming_dist", "mdisp_census_stereo", "mdisp_sad_inte", "mdisp_sad_box",
-    "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_lr_check",
+    "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_sgbm_volume", "mdisp_lr_check",
     "mdisp_build_rectify_maps", "mdisp_remap", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
     "mdisp_census_stereo_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
 ]
@@ -74,6 +74,7 @@ def load():
     lib.mdisp_asw_gifs.argtypes = [vp, img, img, par, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                    vp, img]
     lib.mdisp_sgbm.argtypes = [vp, img, img, sgp, img]
+    lib.mdisp_sgbm_volume.argtypes = [vp, img, img, sgp, vp]
     lib.mdisp_lr_check.argtypes = [vp, img, img, C.c_float, img, img]
     lib.mdisp_build_rectify_maps.argtypes = [P(C.c_double), P(C.c_double), C.c_int, P(C.c_double), P(C.c_double),
                                              C.c_int, C.c_int, vp, vp]

@@ -197,6 +197,14 @@ def sgbm_compute(srcLeft, srcRight, params, ctx=None):
     return out
 
 
+def sgbm_volume(srcLeft, srcRight, params, ctx=None):
+    """Aggregated SGM cost volume S (uint16, H x W x numDisparities, biased by +P2 per path)."""
+    L, R = _u8(srcLeft), _u8(srcRight)
+    S = np.empty(L.shape[:2] + (params.numDisparities,), dtype=np.uint16)
+    check(load().mdisp_sgbm_volume(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(params), S.ctypes.data))
+    return S
+
+
 def getDisparity_SGBM(srcLeft, srcRight, ctx=None):
     """methods/methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7) then `disp / 16`
     (a CV_16S MatExpr divide: round half to even)."""

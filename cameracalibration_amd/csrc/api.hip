@@ -456,6 +456,30 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     return MDISP_OK;
 }
 
+extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* Sh)
+{
+    MD_REQUIRE(c && Sh, MDISP_E_BADARG, "null argument");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    md_sgm_plan pl;
+    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, &pl))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols;
+    const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
+    Carver cv;
+    size_t o_ws = cv.take(pl.total), o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_st = cv.take(p3 * H);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
+    if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
+    const u16* S;
+    if ((rc = md_sgm_aggregate_only(c, pl, base + o_l, base + o_r, pitch, base + o_ws, &S))) return rc;
+    MD_HIP(hipMemcpy2DAsync(Sh, (size_t)pl.D * 2, S, (size_t)pl.sstride * 2, (size_t)pl.D * 2, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LR check, remap, rectification maps
 

@@ -59,11 +59,20 @@ int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* g
 struct md_sgm_plan {
     int H, W, D, minD, maxD, Wp;
     int P1, P2, uniq, maxDiff, npaths, subpixel, costWin, census;
-    size_t off_cL, off_cR, off_pad, off_scratch, off_S, off_aux, total;
+    size_t off_cL, off_cR, off_pad, off_scratch, off_S, off_aux, off_bnd, total;
     size_t pitchL, pitchR;
+    bool use_v2;      // strip-fused two-sweep aggregation (sgm2.hip) instead of per-direction scans
+    int sstride;      // u16 elements per pixel in the S volume
 };
+// sgm2.hip
+bool md_sgm2_supported(const md_sgm_plan& pl);
+size_t md_sgm2_extra_bytes(int H, int W, int batch);
+int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
+                      u16* S, size_t strideS, u8* bndBase, int batch, int naturalOut);
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws);
+// aggregation only; *S receives the device volume (pixel stride plan.sstride)
+int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** S);
 
 // stereo.hip
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,

@@ -11,6 +11,7 @@
 //   L'(p,d) = C(p,d) + min(L'(p-r,d), L'(p-r,d-1)+P1, L'(p-r,d+1)+P1, min_k L'(p-r,k)+P2) - min_k L'(p-r,k)
 // and S' = sum of L' = S + npaths*P2; the bias is removed where S enters the uniqueness ratio.
 #include "common.h"
+#include <stdlib.h>
 
 #define SGM_BIG 0x3FFF0000   // "infinite" path cost for disparities outside [0, D)
 
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void sgm_path_kernel(SgmArgs a, int dx, int dy
 }
 
 struct WtaArgs {
-    const u16* S; int H, W, D, minD;
+    const u16* S; int sstride;      // u16 elements between consecutive pixels of S
+    int H, W, D, minD;
     int bias, uniq, maxDiff, subpixel;
     int16_t* disp; size_t dpitch;   // in elements
 };
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = lane * ND;
     for (int x = wv; x < W; x += 4) {
-        const u16* sp = a.S + ((size_t)y * W + x) * D;
+        const u16* sp = a.S + ((size_t)y * W + x) * a.sstride;
         u32 s[ND];
         u32 best = 0xFFFFFFFFu;
 #pragma unroll
@@ -268,9 +270,13 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan
     plan->off_pad = off; off += plan->pitchR * H;
     plan->off_scratch = off; off += plan->pitchR * H;
     off = md_align(off, 256);
-    plan->off_S = off; off += (size_t)H * W * plan->D * sizeof(u16);
+    plan->use_v2 = md_sgm2_supported(*plan) && !getenv("MDISP_SGM_V1");
+    plan->sstride = plan->use_v2 ? 256 : plan->D;
+    plan->off_S = off; off += (size_t)H * W * plan->sstride * sizeof(u16);
     off = md_align(off, 256);
     plan->off_aux = off; off += 4096;
+    plan->off_bnd = off;
+    if (plan->use_v2) off += md_sgm2_extra_bytes(H, W, 1);
     plan->total = off;
     return MDISP_OK;
 }
@@ -291,7 +297,7 @@ static int launch_paths(hipStream_t s, const md_sgm_plan& pl, const SgmArgs& a)
     return MDISP_OK;
 }
 
-int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws)
+static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws)
 {
     hipStream_t s = ctx->stream;
     u8* base = (u8*)ws;
@@ -313,15 +319,32 @@ int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR
     a.cL = cL; a.pL = pl.pitchL; a.cR = cR; a.pR = pl.pitchR; a.S = S;
     a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD; a.P1 = pl.P1; a.P2 = pl.P2;
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
-    if (pl.D <= 64) rc = launch_paths<1>(s, pl, a);
+    if (pl.use_v2)
+        rc = md_sgm2_aggregate(s, pl, cL, 0, cR, 0, S, 0, base + pl.off_bnd, 1, 1);
+    else if (pl.D <= 64) rc = launch_paths<1>(s, pl, a);
     else if (pl.D <= 128) rc = launch_paths<2>(s, pl, a);
     else if (pl.D <= 256) rc = launch_paths<4>(s, pl, a);
     else rc = launch_paths<8>(s, pl, a);
     if (rc) return rc;
     if (ctx->timing) { MD_HIP(hipEventRecord(ctx->ev[3], s)); ctx->ev_valid[1] = true; }
 
+    return MDISP_OK;
+}
+
+int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** Sout)
+{
+    *Sout = (const u16*)((u8*)ws + pl.off_S);
+    return sgm_aggregate(ctx, pl, dL, dR, pitch, ws);
+}
+
+int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws)
+{
+    hipStream_t s = ctx->stream;
+    u16* S = (u16*)((u8*)ws + pl.off_S);
+    int rc;
+    if ((rc = sgm_aggregate(ctx, pl, dL, dR, pitch, ws))) return rc;
     WtaArgs w;
-    w.S = S; w.H = pl.H; w.W = pl.W; w.D = pl.D; w.minD = pl.minD;
+    w.S = S; w.sstride = pl.sstride; w.H = pl.H; w.W = pl.W; w.D = pl.D; w.minD = pl.minD;
     w.bias = pl.npaths * pl.P2; w.uniq = pl.uniq; w.maxDiff = pl.maxDiff; w.subpixel = pl.subpixel;
     w.disp = dDisp; w.dpitch = pl.W;
     size_t lds = (size_t)pl.W * 4 + (size_t)pl.W * 2 + 16;

@@ -165,6 +165,12 @@ int mdisp_asw_gifs(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const
  * L/R CV_8UC1; out CV_16S HxW, fixed point x16, invalid = (minDisparity-1)*16. */
 int mdisp_sgbm(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out);
 
+/* The aggregated SGM cost volume S(y,x,d) = sum over paths of L_r, biased by +P2 per path (see the
+ * recursion note in the README of the library sources), as uint16 [rows][cols][numDisparities] in host
+ * memory.  No counterpart call in the reference (StereoSGBM keeps S private); exported so that
+ * the path recursion can be checked value by value. */
+int mdisp_sgbm_volume(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* S);
+
 /* LR consistency check of PatchMatch::postProcess, methods/patchmatch.cpp:817-828.
  * dL/dR CV_32F, validL/validR CV_8U (1 = consistent within `thresh`). */
 int mdisp_lr_check(mdisp_ctx*, const mdisp_image* dL, const mdisp_image* dR, float thresh,
