@@ -39,6 +39,7 @@ EXPORTS = [
     "mdisp_census_transform", "mdisp_hamming_dist", "mdisp_census_stereo", "mdisp_sad_inte", "mdisp_sad_box",
     "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_sgbm_volume", "mdisp_lr_check",
     "mdisp_build_rectify_maps", "mdisp_remap", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
+    "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
     "mdisp_census_stereo_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
 ]
 
@@ -82,6 +83,9 @@ def load():
     lib.mdisp_sgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, sgp]
     lib.mdisp_sgbm_workspace_bytes.restype = C.c_size_t
     lib.mdisp_sgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
+    lib.mdisp_sgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, sgp]
+    lib.mdisp_sgbm_batch_workspace_bytes.restype = C.c_size_t
+    lib.mdisp_sgbm_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_census_stereo_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]

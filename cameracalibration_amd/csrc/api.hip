@@ -410,8 +410,34 @@ extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
 extern "C" size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p)
 {
     md_sgm_plan pl;
-    if (md_sgm_plan_make(rows, cols, p, &pl)) return 0;
+    if (md_sgm_plan_make(rows, cols, p, 1, &pl)) return 0;
     return pl.total;
+}
+
+extern "C" size_t mdisp_sgbm_batch_workspace_bytes(int rows, int cols, int batch, const mdisp_sgbm_params* p)
+{
+    md_sgm_plan pl;
+    if (md_sgm_plan_make(rows, cols, p, batch, &pl)) return 0;
+    return pl.total;
+}
+
+extern "C" int mdisp_sgbm_batch_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int batch, size_t pair_stride,
+                                    int rows, int cols, size_t pitch, const mdisp_sgbm_params* p, int16_t* d_disp,
+                                    void* d_workspace, size_t workspace_bytes)
+{
+    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(pitch >= (size_t)cols && (batch == 1 || pair_stride >= pitch * rows), MDISP_E_BADARG, "bad pitch / pair stride");
+    md_sgm_plan pl;
+    int rc;
+    if ((rc = md_sgm_plan_make(rows, cols, p, batch, &pl))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    void* ws = d_workspace;
+    if (ws) MD_REQUIRE(workspace_bytes >= pl.total, MDISP_E_BADARG, "workspace too small: %zu < %zu", workspace_bytes, pl.total);
+    else { ws = mdisp_ws(c, pl.total); if (!ws) return MDISP_E_NOMEM; }
+    if (c->timing) MD_HIP(hipEventRecord(c->ev[0], c->stream));
+    if ((rc = md_sgm_run(c, pl, d_left, d_right, pitch, pair_stride, d_disp, ws))) return rc;
+    if (c->timing) { MD_HIP(hipEventRecord(c->ev[1], c->stream)); c->ev_valid[0] = true; }
+    return MDISP_OK;
 }
 
 extern "C" int mdisp_sgbm_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
@@ -419,17 +445,7 @@ extern "C" int mdisp_sgbm_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t
 {
     MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
     MD_REQUIRE(pitch >= (size_t)cols, MDISP_E_BADARG, "pitch smaller than a row");
-    md_sgm_plan pl;
-    int rc;
-    if ((rc = md_sgm_plan_make(rows, cols, p, &pl))) return rc;
-    MD_HIP(hipSetDevice(c->device));
-    void* ws = d_workspace;
-    if (ws) MD_REQUIRE(workspace_bytes >= pl.total, MDISP_E_BADARG, "workspace too small: %zu < %zu", workspace_bytes, pl.total);
-    else { ws = mdisp_ws(c, pl.total); if (!ws) return MDISP_E_NOMEM; }
-    if (c->timing) MD_HIP(hipEventRecord(c->ev[0], c->stream));
-    if ((rc = md_sgm_run(c, pl, d_left, d_right, pitch, d_disp, ws))) return rc;
-    if (c->timing) { MD_HIP(hipEventRecord(c->ev[1], c->stream)); c->ev_valid[0] = true; }
-    return MDISP_OK;
+    return mdisp_sgbm_batch_dev(c, d_left, d_right, 1, 0, rows, cols, pitch, p, d_disp, d_workspace, workspace_bytes);
 }
 
 extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out)
@@ -440,7 +456,7 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
     if ((rc = check_out(out, L->rows, L->cols, MDISP_16S, 1, "out"))) return rc;
     md_sgm_plan pl;
-    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, &pl))) return rc;
+    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, 1, &pl))) return rc;
     MD_HIP(hipSetDevice(c->device));
     const int H = L->rows, W = L->cols;
     const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
@@ -450,7 +466,7 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     if (!base) return MDISP_E_NOMEM;
     if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
     if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
-    if ((rc = md_sgm_run(c, pl, base + o_l, base + o_r, pitch, (int16_t*)(base + o_d), base + o_ws))) return rc;
+    if ((rc = md_sgm_run(c, pl, base + o_l, base + o_r, pitch, 0, (int16_t*)(base + o_d), base + o_ws))) return rc;
     MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, c->stream));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
@@ -463,7 +479,7 @@ extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp
     if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
     MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
     md_sgm_plan pl;
-    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, &pl))) return rc;
+    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, 1, &pl))) return rc;
     MD_HIP(hipSetDevice(c->device));
     const int H = L->rows, W = L->cols;
     const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);

@@ -61,16 +61,20 @@ struct md_sgm_plan {
     int P1, P2, uniq, maxDiff, npaths, subpixel, costWin, census;
     size_t off_cL, off_cR, off_pad, off_scratch, off_S, off_aux, off_bnd, total;
     size_t pitchL, pitchR;
+    int batch;        // stereo pairs processed per call
+    size_t strideS;   // u16 elements between the S volumes of consecutive pairs
     bool use_v2;      // strip-fused two-sweep aggregation (sgm2.hip) instead of per-direction scans
     int sstride;      // u16 elements per pixel in the S volume
 };
 // sgm2.hip
 bool md_sgm2_supported(const md_sgm_plan& pl);
-size_t md_sgm2_extra_bytes(int H, int W, int batch);
+size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode);
+bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
                       u16* S, size_t strideS, u8* bndBase, int batch, int naturalOut);
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan);
-int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws);
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
+int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
+               int16_t* dDisp, void* ws);
 // aggregation only; *S receives the device volume (pixel stride plan.sstride)
 int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** S);
 

@@ -166,6 +166,7 @@ struct WtaArgs {
     int H, W, D, minD;
     int bias, uniq, maxDiff, subpixel;
     int16_t* disp; size_t dpitch;   // in elements
+    size_t strideS, strideDisp;     // per-pair strides in elements (blockIdx.y = pair)
 };
 
 // One workgroup per image row.  Phase 1 (one wave per pixel, pixels strided over the 4 waves):
@@ -181,12 +182,14 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
     const int y = blockIdx.x;
     const int W = a.W, D = a.D;
     const int INVALID = (a.minD - 1) * 16;
+    const u16* Sbase = a.S + (size_t)blockIdx.y * a.strideS;
+    int16_t* dispBase = a.disp + (size_t)blockIdx.y * a.strideDisp;
     for (int i = threadIdx.x; i < W; i += 256) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = lane * ND;
     for (int x = wv; x < W; x += 4) {
-        const u16* sp = a.S + ((size_t)y * W + x) * a.sstride;
+        const u16* sp = Sbase + ((size_t)y * W + x) * a.sstride;
         u32 s[ND];
         u32 best = 0xFFFFFFFFu;
 #pragma unroll
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
             const int _d = v >> 4, d_ = (v + 15) >> 4;
             if (inconsistent(x - _d, _d) && inconsistent(x - d_, d_)) v = INVALID;
         }
-        a.disp[(size_t)y * a.dpitch + x] = (int16_t)v;
+        dispBase[(size_t)y * a.dpitch + x] = (int16_t)v;
     }
 }
 
@@ -240,8 +243,10 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
 
 static const int DIRS[8][2] = {{+1, 0}, {-1, 0}, {0, +1}, {0, -1}, {+1, +1}, {-1, +1}, {+1, -1}, {-1, -1}};
 
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan)
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan)
 {
+    MD_REQUIRE(batch >= 1 && batch <= 4096, MDISP_E_BADARG, "batch must be in 1..4096");
+    plan->batch = batch;
     MD_REQUIRE(p && plan, MDISP_E_BADARG, "null SGM parameters");
     MD_REQUIRE(H >= 3 && W >= 3 && W <= 65535, MDISP_E_BADARG, "image size %dx%d unsupported", W, H);
     MD_REQUIRE(p->numDisparities > 0 && p->numDisparities <= 512 && p->minDisparity >= 0, MDISP_E_BADARG,
@@ -264,19 +269,21 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, md_sgm_plan* plan
                "npaths*(Cmax+P2) exceeds the 16-bit path-cost range");
     plan->pitchL = md_align((size_t)W, 256);
     plan->pitchR = md_align((size_t)plan->Wp, 256);
+    // per-pair arrays are replicated `batch` times, back to back
     size_t off = 0;
-    plan->off_cL = off; off += plan->pitchL * H;
-    plan->off_cR = off; off += plan->pitchR * H;
+    plan->off_cL = off; off += plan->pitchL * H * batch;
+    plan->off_cR = off; off += plan->pitchR * H * batch;
     plan->off_pad = off; off += plan->pitchR * H;
     plan->off_scratch = off; off += plan->pitchR * H;
     off = md_align(off, 256);
     plan->use_v2 = md_sgm2_supported(*plan) && !getenv("MDISP_SGM_V1");
     plan->sstride = plan->use_v2 ? 256 : plan->D;
-    plan->off_S = off; off += (size_t)H * W * plan->sstride * sizeof(u16);
+    plan->strideS = md_align((size_t)H * W * plan->sstride * sizeof(u16), 256) / sizeof(u16);
+    plan->off_S = off; off += plan->strideS * sizeof(u16) * batch;
     off = md_align(off, 256);
     plan->off_aux = off; off += 4096;
     plan->off_bnd = off;
-    if (plan->use_v2) off += md_sgm2_extra_bytes(H, W, 1);
+    if (plan->use_v2) off += md_sgm2_extra_bytes(H, W, batch, md_sgm2_u8(*plan));
     plan->total = off;
     return MDISP_OK;
 }
@@ -297,62 +304,74 @@ static int launch_paths(hipStream_t s, const md_sgm_plan& pl, const SgmArgs& a)
     return MDISP_OK;
 }
 
-static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws)
+// dL/dR: first pair; pair i lives at +i*pairStride bytes
+static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws)
 {
     hipStream_t s = ctx->stream;
     u8* base = (u8*)ws;
-    u8* cL = base + pl.off_cL; u8* cR = base + pl.off_cR; u8* pad = base + pl.off_pad; u8* scr = base + pl.off_scratch;
+    u8* pad = base + pl.off_pad; u8* scr = base + pl.off_scratch;
     u16* S = (u16*)(base + pl.off_S);
+    const size_t strideL = pl.pitchL * pl.H, strideR = pl.pitchR * pl.H;
     int rc;
-    // census of the left image needs rows padded to 4 bytes: stage it through the pad buffer when
-    // the caller's pitch is not a multiple of 4
-    const u8* srcL = dL; size_t spL = pitch;
-    if (pitch % 4 != 0 || pitch < md_align(pl.W, 4)) {
-        MD_HIP(hipMemcpy2DAsync(scr, pl.pitchL, dL, pitch, pl.W, pl.H, hipMemcpyDeviceToDevice, s));
-        srcL = scr; spL = pl.pitchL;
+    for (int i = 0; i < pl.batch; i++) {
+        u8* cL = base + pl.off_cL + (size_t)i * strideL; u8* cR = base + pl.off_cR + (size_t)i * strideR;
+        const u8* pL = dL + (size_t)i * pairStride; const u8* pR = dR + (size_t)i * pairStride;
+        // census reads rows as dwords: stage the left image when the caller's pitch is not a multiple of 4
+        const u8* srcL = pL; size_t spL = pitch;
+        if (pitch % 4 != 0 || pitch < md_align(pl.W, 4)) {
+            MD_HIP(hipMemcpy2DAsync(scr, pl.pitchL, pL, pitch, pl.W, pl.H, hipMemcpyDeviceToDevice, s));
+            srcL = scr; spL = pl.pitchL;
+        }
+        if ((rc = md_census(s, srcL, spL, pl.H, pl.W, pl.census, pl.costWin, cL, pl.pitchL, nullptr))) return rc;
+        if ((rc = md_pad_reflect_lr(s, pR, pitch, pl.H, pl.W, pl.maxD, 0, pad, pl.pitchR))) return rc;
+        if ((rc = md_census(s, pad, pl.pitchR, pl.H, pl.Wp, pl.census, pl.costWin, cR, pl.pitchR, nullptr))) return rc;
     }
-    if ((rc = md_census(s, srcL, spL, pl.H, pl.W, pl.census, pl.costWin, cL, pl.pitchL, nullptr))) return rc;
-    if ((rc = md_pad_reflect_lr(s, dR, pitch, pl.H, pl.W, pl.maxD, 0, pad, pl.pitchR))) return rc;
-    if ((rc = md_census(s, pad, pl.pitchR, pl.H, pl.Wp, pl.census, pl.costWin, cR, pl.pitchR, nullptr))) return rc;
-
-    SgmArgs a;
-    a.cL = cL; a.pL = pl.pitchL; a.cR = cR; a.pR = pl.pitchR; a.S = S;
-    a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD; a.P1 = pl.P1; a.P2 = pl.P2;
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
-    if (pl.use_v2)
-        rc = md_sgm2_aggregate(s, pl, cL, 0, cR, 0, S, 0, base + pl.off_bnd, 1, 1);
-    else if (pl.D <= 64) rc = launch_paths<1>(s, pl, a);
-    else if (pl.D <= 128) rc = launch_paths<2>(s, pl, a);
-    else if (pl.D <= 256) rc = launch_paths<4>(s, pl, a);
-    else rc = launch_paths<8>(s, pl, a);
-    if (rc) return rc;
+    if (pl.use_v2) {
+        rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch, 1);
+        if (rc) return rc;
+    } else {
+        for (int i = 0; i < pl.batch; i++) {
+            SgmArgs a;
+            a.cL = base + pl.off_cL + (size_t)i * strideL; a.pL = pl.pitchL;
+            a.cR = base + pl.off_cR + (size_t)i * strideR; a.pR = pl.pitchR; a.S = S + (size_t)i * pl.strideS;
+            a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD; a.P1 = pl.P1; a.P2 = pl.P2;
+            if (pl.D <= 64) rc = launch_paths<1>(s, pl, a);
+            else if (pl.D <= 128) rc = launch_paths<2>(s, pl, a);
+            else if (pl.D <= 256) rc = launch_paths<4>(s, pl, a);
+            else rc = launch_paths<8>(s, pl, a);
+            if (rc) return rc;
+        }
+    }
     if (ctx->timing) { MD_HIP(hipEventRecord(ctx->ev[3], s)); ctx->ev_valid[1] = true; }
-
     return MDISP_OK;
 }
 
 int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** Sout)
 {
     *Sout = (const u16*)((u8*)ws + pl.off_S);
-    return sgm_aggregate(ctx, pl, dL, dR, pitch, ws);
+    return sgm_aggregate(ctx, pl, dL, dR, pitch, 0, ws);
 }
 
-int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, int16_t* dDisp, void* ws)
+int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
+               int16_t* dDisp, void* ws)
 {
     hipStream_t s = ctx->stream;
     u16* S = (u16*)((u8*)ws + pl.off_S);
     int rc;
-    if ((rc = sgm_aggregate(ctx, pl, dL, dR, pitch, ws))) return rc;
+    if ((rc = sgm_aggregate(ctx, pl, dL, dR, pitch, pairStride, ws))) return rc;
     WtaArgs w;
     w.S = S; w.sstride = pl.sstride; w.H = pl.H; w.W = pl.W; w.D = pl.D; w.minD = pl.minD;
     w.bias = pl.npaths * pl.P2; w.uniq = pl.uniq; w.maxDiff = pl.maxDiff; w.subpixel = pl.subpixel;
     w.disp = dDisp; w.dpitch = pl.W;
+    w.strideS = pl.strideS; w.strideDisp = (size_t)pl.H * pl.W;
     size_t lds = (size_t)pl.W * 4 + (size_t)pl.W * 2 + 16;
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[4], s));
-    if (pl.D <= 64) sgm_wta_kernel<1><<<pl.H, 256, lds, s>>>(w);
-    else if (pl.D <= 128) sgm_wta_kernel<2><<<pl.H, 256, lds, s>>>(w);
-    else if (pl.D <= 256) sgm_wta_kernel<4><<<pl.H, 256, lds, s>>>(w);
-    else sgm_wta_kernel<8><<<pl.H, 256, lds, s>>>(w);
+    dim3 gw(pl.H, pl.batch);
+    if (pl.D <= 64) sgm_wta_kernel<1><<<gw, 256, lds, s>>>(w);
+    else if (pl.D <= 128) sgm_wta_kernel<2><<<gw, 256, lds, s>>>(w);
+    else if (pl.D <= 256) sgm_wta_kernel<4><<<gw, 256, lds, s>>>(w);
+    else sgm_wta_kernel<8><<<gw, 256, lds, s>>>(w);
     MD_HIP(hipGetLastError());
     if (ctx->timing) { MD_HIP(hipEventRecord(ctx->ev[5], s)); ctx->ev_valid[2] = true; }
     return MDISP_OK;

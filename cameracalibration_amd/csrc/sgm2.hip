@@ -1,16 +1,20 @@
 // Strip-fused semi-global matching for gfx950 (same arithmetic as sgm.hip, far less HBM traffic).
 //
 // The eight path directions are folded into two sweeps over the image:
-//   down sweep:  ->  (1,0),  v (0,1),  \ (1,1),  / (-1,1)     writes the 4-path partial sum S4 (u16)
-//   up sweep:    <- (-1,0),  ^ (0,-1), (1,-1), (-1,-1)        reads S4, finishes S8 in registers
+//   down sweep:  v (0,1),  \ (1,1),  / (-1,1)   + the stored (1,0) path   -> 4-path partial sum S4 (u16)
+//   up sweep:    ^ (0,-1), (1,-1), (-1,-1)       + the stored (-1,0) path  -> S4 + 4 = S8, in registers
 // so the aggregated volume crosses HBM once in each direction (2 B written + 2 B read per
 // (x,y,d)) instead of being read-modify-written by every direction.
 //
-// A workgroup owns a strip of 16 image columns for the whole image height.  Vertical and diagonal
-// path states live in registers / LDS and advance row by row; the horizontal path of a block of 16
-// rows is scanned across the strip first.  What a strip cannot know locally -- the state of the
-// horizontal and diagonal paths where they ENTER the strip -- is produced by a pre-pass that runs
-// those six directions along their whole lines and keeps only the states at strip borders.
+// Kernels:
+//   hscan    one lane-row per (image row, direction): the two horizontal paths over whole rows,
+//            stored as a byte volume (their values never exceed Cmax + P2) or, for large P2, u16.
+//   prepass  the four diagonal directions along their whole lines, keeping only the normalised
+//            path state where a line crosses from one 16-column strip into the next.
+//   sweep    a workgroup owns a strip of 16 columns for the whole image height; lane-row <-> column.
+//            The vertical path state lives in registers, the two diagonal states travel through
+//            LDS from the neighbouring column of the previous row (strip edges read the prepass
+//            states), the horizontal path is read back from hscan's volume.
 //
 // Lane mapping: a "lane-row" of 16 lanes (one DPP row) owns one pixel at a time; each lane holds 16
 // consecutive disparities as 8 registers of packed u16 pairs, interleaved as
@@ -63,13 +67,14 @@ struct Sgm2Args {
     const u8* cL; size_t pL, strideL;     // census of the left image      [B][H][pL]
     const u8* cR; size_t pR, strideR;     // census of the padded right    [B][H][pR]
     u16* S; size_t strideS;               // partial sums                  [B][H][W][256] (register order)
-    u16* bnd[6]; size_t strideB;          // strip-border path states      [B][H][nstrips][256]
+    u16* bnd[4]; size_t strideB;          // strip-border diagonal states  [B][H][nstrips][256]
+    u8* Hvol[2]; size_t strideH;          // horizontal path volumes (1,0) and (-1,0): [B][H][W][256] u8 or u16
     int H, W, D, minD, maxD, nstrips;
     u32 P1P1, P2P2;
     int tail;                             // 1 when D < 256: disparities >= D are masked off
     int naturalOut;                       // up sweep: store S8 in natural d order (for the separate WTA kernel)
 };
-// order of bnd[]: 0 (1,0)  1 (-1,0)  2 (1,1)  3 (-1,1)  4 (1,-1)  5 (-1,-1)
+// order of bnd[]: 0 (1,1)  1 (-1,1)  2 (1,-1)  3 (-1,-1)
 
 // masks that pin disparities >= D of this lane to "infinite"
 __device__ __forceinline__ void make_tail(int lic, int D, u32 (&tail)[NR])
@@ -153,10 +158,67 @@ __device__ __forceinline__ void zero8(u32 (&v)[NR])
     for (int r = 0; r < NR; r++) v[r] = 0;
 }
 
+// path values L' (<= Cmax + P2 <= 255) of one lane as 16 bytes in natural d order, and back
+__device__ __forceinline__ uint4 pack_bytes(const u32 (&L)[NR])
+{
+    uint4 w;
+    w.x = __builtin_amdgcn_perm(L[1], L[0], 0x06020400u);   // [A.lo, B.lo, A.hi, B.hi] = e 0,1,2,3
+    w.y = __builtin_amdgcn_perm(L[3], L[2], 0x06020400u);
+    w.z = __builtin_amdgcn_perm(L[5], L[4], 0x06020400u);
+    w.w = __builtin_amdgcn_perm(L[7], L[6], 0x06020400u);
+    return w;
+}
+__device__ __forceinline__ void unpack_bytes(const uint4& w, u32 (&L)[NR])
+{
+    const u32 v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        L[2 * g] = __builtin_amdgcn_perm(v[g], v[g], 0x0C020C00u);       // [e 4g   | e 4g+2]
+        L[2 * g + 1] = __builtin_amdgcn_perm(v[g], v[g], 0x0C030C01u);   // [e 4g+1 | e 4g+3]
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// Pre-pass: run a path along its whole line and keep the state wherever it leaves a strip.
-// One lane-row per line, 16 lines per workgroup.  Line ids: [0,H) (1,0); [H,2H) (-1,0); then the four
-// diagonal directions with W+H-1 lines each in the order (1,1) (-1,1) (1,-1) (-1,-1).
+// Horizontal paths: one lane-row per (row, direction), 16 per workgroup; line id < H: (1,0), else (-1,0).
+template <bool TAIL, bool U8>
+__global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
+{
+    const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
+    const int pair = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int line = blockIdx.x * 16 + lr;
+    if (line >= 2 * H) return;
+    const int dir = line >= H, y = line - dir * H;
+    const int dx = dir ? -1 : 1;
+    int x = dir ? W - 1 : 0;
+    const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
+    const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR;
+    u8* hrow = a.Hvol[dir] + (size_t)pair * a.strideH + (size_t)y * W * (U8 ? 256 : 512) + lic * (U8 ? 16 : 32);
+    u32 tail[NR];
+    make_tail(lic, a.D, tail);
+    u32 N[NR];
+    zero8(N);                        // predecessor outside the image: all path costs equal
+    if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) N[r] |= tail[r];
+    }
+    u32 cl; uint4 rb;
+    load_cost_operands(a, cLrow, cRrow, x, lic, cl, rb);
+    for (int t = 0; t < W; t++) {
+        u32 C[NR], L[NR];
+        cost_from_operands(cl, rb, C);
+        if (t + 1 < W) load_cost_operands(a, cLrow, cRrow, x + dx, lic, cl, rb);
+        sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
+        if (U8) *reinterpret_cast<uint4*>(hrow + (size_t)x * 256) = pack_bytes(L);
+        else store8(reinterpret_cast<u16*>(hrow + (size_t)x * 512), L);
+        x += dx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal pre-pass: run a path along its whole line and keep the state wherever it leaves a strip.
+// One lane-row per line, 16 lines per workgroup; W+H-1 lines per direction, directions in the
+// order (1,1) (-1,1) (1,-1) (-1,-1).
 template <bool TAIL>
 __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 {
@@ -164,34 +226,24 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
     const int pair = blockIdx.y;
     const int H = a.H, W = a.W;
     const int nd = W + H - 1;
-    int line = blockIdx.x * 16 + lr;
-    const int total = 2 * H + 4 * nd;
-    if (line >= total) return;
-    int dir, dx, dy, x, y;
-    if (line < 2 * H) {
-        dir = line / H; y = line - dir * H; dy = 0; dx = dir == 0 ? 1 : -1; x = dx > 0 ? 0 : W - 1;
-    } else {
-        line -= 2 * H;
-        const int q = line / nd, i = line - q * nd;
-        dir = 2 + q;
-        dx = (q & 1) ? -1 : 1; dy = (q & 2) ? -1 : 1;
+    const int line = blockIdx.x * 16 + lr;
+    if (line >= 4 * nd) return;
+    const int q = line / nd, i = line - q * nd;
+    const int dx = (q & 1) ? -1 : 1, dy = (q & 2) ? -1 : 1;
+    int x, y;
+    {
         const int ys = dy > 0 ? 0 : H - 1;
         if (i < W) { x = i; y = ys; }
         else { const int j = i - W; y = dy > 0 ? 1 + j : H - 2 - j; x = dx > 0 ? 0 : W - 1; }
     }
-    int n;
-    {
-        const int nx = dx > 0 ? W - x : x + 1;
-        const int ny = dy > 0 ? H - y : (dy < 0 ? y + 1 : 0x7FFFFFFF);
-        n = min(nx, ny);
-    }
+    const int n = min(dx > 0 ? W - x : x + 1, dy > 0 ? H - y : y + 1);
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
-    u16* bnd = a.bnd[dir] + (size_t)pair * a.strideB;
+    u16* bnd = a.bnd[q] + (size_t)pair * a.strideB;
     u32 tail[NR];
     make_tail(lic, a.D, tail);
     u32 N[NR];
-    zero8(N);                        // predecessor outside the image: all path costs equal
+    zero8(N);
     if (TAIL) {
 #pragma unroll
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
@@ -217,9 +269,9 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Main sweep.  UP = false: paths (1,0) (0,1) (1,1) (-1,1), top to bottom, S <- sum of the four.
-//              UP = true : paths (-1,0) (0,-1) (1,-1) (-1,-1), bottom to top, S <- S + sum.
-template <bool UP, bool TAIL>
+// Main sweep.  UP = false: (0,1) (1,1) (-1,1) top to bottom, S <- H(1,0) + the three.
+//              UP = true : (0,-1) (1,-1) (-1,-1) bottom to top, S8 = S + H(-1,0) + the three.
+template <bool UP, bool TAIL, bool U8>
 __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 {
     __shared__ u32 diag[2][2][CW][128];   // [row parity][x-1 / x+1 family][column][packed pairs]
@@ -231,9 +283,9 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
     u16* Sp = a.S + (size_t)pair * a.strideS;
-    const u16* bH = a.bnd[UP ? 1 : 0] + (size_t)pair * a.strideB;   // horizontal path entering the strip
-    const u16* bA = a.bnd[UP ? 4 : 2] + (size_t)pair * a.strideB;   // diagonal with dx = +1 (predecessor at x-1)
-    const u16* bB = a.bnd[UP ? 5 : 3] + (size_t)pair * a.strideB;   // diagonal with dx = -1 (predecessor at x+1)
+    const u8* Hp = a.Hvol[UP ? 1 : 0] + (size_t)pair * a.strideH;
+    const u16* bA = a.bnd[UP ? 2 : 0] + (size_t)pair * a.strideB;   // diagonal with dx = +1 (predecessor at x-1)
+    const u16* bB = a.bnd[UP ? 3 : 1] + (size_t)pair * a.strideB;   // diagonal with dx = -1 (predecessor at x+1)
     u32 tail[NR];
     make_tail(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
@@ -244,125 +296,102 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 #pragma unroll
         for (int r = 0; r < NR; r++) Nv[r] |= tail[r];
     }
-    const int nblocks = (H + RB - 1) / RB;
-    for (int jb = 0; jb < nblocks; jb++) {
-        // rows of this block in processing order: ys, ys + sy, ...
-        const int ys = UP ? H - 1 - jb * RB : jb * RB;
-        const int sy = UP ? -1 : 1;
-        const int nrows = min(RB, H - jb * RB);
-
-        // ---- phase A: horizontal path, lane-row <-> image row, scanned across the strip ----
-        if (lr < nrows) {
-            const int y = ys + sy * lr;
-            const u8* cLrow = cLp + (size_t)y * a.pL;
-            const u8* cRrow = cRp + (size_t)y * a.pR;
-            u32 N[NR];
-            const bool fromImageBorder = UP ? (x0 + cw >= W) : (x0 == 0);
-            if (fromImageBorder) {
-                zero8(N);
+    const int x = x0 + lr;
+    const bool colActive = lr < cw;
+    const int sy = UP ? -1 : 1, ys = UP ? H - 1 : 0;
+    // which strip-border state this lane-row consumes (none for interior columns)
+    const bool edgeA = lr == 0 && x != 0;              // predecessor x-1 belongs to the strip on the left
+    const bool edgeB = lr == cw - 1 && x != W - 1;     // predecessor x+1 belongs to the strip on the right
+    // operands of the next row are requested before the current row is computed
+    u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0); u32 Snext[NR], Hnext[NR], BnA[NR], BnB[NR];
+    auto fetch_row = [&](int r) {
+        const int y = ys + sy * r;
+        load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
+        const size_t pix = (size_t)y * W + x;
+        if (U8) hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
+        else load8(reinterpret_cast<const u16*>(Hp + pix * 512) + lic * DPL, Hnext);
+        if (UP) load8(Sp + (pix * 256 + lic * DPL), Snext);
+        if (r > 0) {
+            if (edgeA) load8(bA + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnA);
+            if (edgeB) load8(bB + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnB);
+        }
+    };
+    if (colActive) fetch_row(0);
+    for (int r = 0; r < H; r++) {
+        const int y = ys + sy * r;
+        const bool hasPrevRow = r > 0;
+        const int par = r & 1;
+        if (colActive) {
+            u16* sp = Sp + (((size_t)y * W + x) * 256 + lic * DPL);
+            u32 C[NR], L[NR], Sacc[NR], NA[NR], NB[NR];
+            cost_from_operands(cl, rb, C);
+            if (U8) unpack_bytes(hb, Sacc);
+            else {
+#pragma unroll
+                for (int q = 0; q < NR; q++) Sacc[q] = Hnext[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+                if (UP) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+                NA[q] = BnA[q]; NB[q] = BnB[q];
+            }
+            if (r + 1 < H) fetch_row(r + 1);
+            // vertical
+            sgm_step<TAIL>(Nv, C, P1P1, P2P2, tail, L);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            // diagonal arriving from (x-1, previous row)
+            if (!hasPrevRow || x == 0) {
+                zero8(NA);
                 if (TAIL) {
 #pragma unroll
-                    for (int r = 0; r < NR; r++) N[r] |= tail[r];
+                    for (int q = 0; q < NR; q++) NA[q] |= tail[q];
                 }
-            } else load8(bH + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), N);
-            int x = UP ? x0 + cw - 1 : x0;
-            const int dx = UP ? -1 : 1;
-            u32 cl; uint4 rb;
-            load_cost_operands(a, cLrow, cRrow, x, lic, cl, rb);
-            for (int t = 0; t < cw; t++) {
-                u32 C[NR], L[NR];
-                cost_from_operands(cl, rb, C);
-                u16* sp = Sp + (((size_t)y * W + x) * 256 + lic * DPL);
-                u32 Sold[NR];
-                if (UP) load8(sp, Sold);
-                if (t + 1 < cw) load_cost_operands(a, cLrow, cRrow, x + dx, lic, cl, rb);
-                sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
-                if (UP) {
-#pragma unroll
-                    for (int r = 0; r < NR; r++) L[r] = pkadd(L[r], Sold[r]);
-                }
-                store8(sp, L);
-                x += dx;
+            } else if (lr != 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][0][lr - 1][lic * 8]);
+                const uint4 v0 = src[0], v1 = src[1];
+                NA[0] = v0.x; NA[1] = v0.y; NA[2] = v0.z; NA[3] = v0.w; NA[4] = v1.x; NA[5] = v1.y; NA[6] = v1.z; NA[7] = v1.w;
             }
-        }
-        __syncthreads();   // the horizontal sums of the block are read back by other waves below
-
-        // ---- phase B: vertical and diagonal paths, lane-row <-> column ----
-        const int x = x0 + lr;
-        const bool colActive = lr < cw;
-        for (int r = 0; r < nrows; r++) {
-            const int y = ys + sy * r;
-            const int yp = y - sy;                           // predecessor row
-            const bool hasPrevRow = yp >= 0 && yp < H;
-            const int par = r & 1;
-            if (colActive) {
-                u32 cl; uint4 rb;
-                load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
-                u16* sp = Sp + (((size_t)y * W + x) * 256 + lic * DPL);
-                u32 Sacc[NR];
-                load8(sp, Sacc);
-                u32 C[NR], L[NR];
-                cost_from_operands(cl, rb, C);
-                // vertical
-                sgm_step<TAIL>(Nv, C, P1P1, P2P2, tail, L);
+            sgm_step<TAIL>(NA, C, P1P1, P2P2, tail, L);
 #pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                // diagonal arriving from (x-1, yp)
-                u32 Nd[NR];
-                if (!hasPrevRow || x == 0) {
-                    zero8(Nd);
-                    if (TAIL) {
-#pragma unroll
-                        for (int q = 0; q < NR; q++) Nd[q] |= tail[q];
-                    }
-                } else if (lr == 0) load8(bA + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), Nd);
-                else {
-                    const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][0][lr - 1][lic * 8]);
-                    const uint4 v0 = src[0], v1 = src[1];
-                    Nd[0] = v0.x; Nd[1] = v0.y; Nd[2] = v0.z; Nd[3] = v0.w; Nd[4] = v1.x; Nd[5] = v1.y; Nd[6] = v1.z; Nd[7] = v1.w;
-                }
-                sgm_step<TAIL>(Nd, C, P1P1, P2P2, tail, L);
-#pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                {
-                    uint4* dst = reinterpret_cast<uint4*>(&diag[par][0][lr][lic * 8]);
-                    dst[0] = make_uint4(Nd[0], Nd[1], Nd[2], Nd[3]);
-                    dst[1] = make_uint4(Nd[4], Nd[5], Nd[6], Nd[7]);
-                }
-                // diagonal arriving from (x+1, yp)
-                if (!hasPrevRow || x == W - 1) {
-                    zero8(Nd);
-                    if (TAIL) {
-#pragma unroll
-                        for (int q = 0; q < NR; q++) Nd[q] |= tail[q];
-                    }
-                } else if (lr == cw - 1) load8(bB + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), Nd);
-                else {
-                    const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][1][lr + 1][lic * 8]);
-                    const uint4 v0 = src[0], v1 = src[1];
-                    Nd[0] = v0.x; Nd[1] = v0.y; Nd[2] = v0.z; Nd[3] = v0.w; Nd[4] = v1.x; Nd[5] = v1.y; Nd[6] = v1.z; Nd[7] = v1.w;
-                }
-                sgm_step<TAIL>(Nd, C, P1P1, P2P2, tail, L);
-#pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                {
-                    uint4* dst = reinterpret_cast<uint4*>(&diag[par][1][lr][lic * 8]);
-                    dst[0] = make_uint4(Nd[0], Nd[1], Nd[2], Nd[3]);
-                    dst[1] = make_uint4(Nd[4], Nd[5], Nd[6], Nd[7]);
-                }
-                if (UP && a.naturalOut) {
-                    // [A_g.lo|B_g.lo], [A_g.hi|B_g.hi]: pairs of consecutive disparities
-                    u32 nat[NR];
-#pragma unroll
-                    for (int g = 0; g < NR / 2; g++) {
-                        nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
-                        nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
-                    }
-                    store8(sp, nat);
-                } else store8(sp, Sacc);
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            {
+                uint4* dst = reinterpret_cast<uint4*>(&diag[par][0][lr][lic * 8]);
+                dst[0] = make_uint4(NA[0], NA[1], NA[2], NA[3]);
+                dst[1] = make_uint4(NA[4], NA[5], NA[6], NA[7]);
             }
-            __syncthreads();   // diag[par] complete before the next row reads it
+            // diagonal arriving from (x+1, previous row)
+            if (!hasPrevRow || x == W - 1) {
+                zero8(NB);
+                if (TAIL) {
+#pragma unroll
+                    for (int q = 0; q < NR; q++) NB[q] |= tail[q];
+                }
+            } else if (lr != cw - 1) {
+                const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][1][lr + 1][lic * 8]);
+                const uint4 v0 = src[0], v1 = src[1];
+                NB[0] = v0.x; NB[1] = v0.y; NB[2] = v0.z; NB[3] = v0.w; NB[4] = v1.x; NB[5] = v1.y; NB[6] = v1.z; NB[7] = v1.w;
+            }
+            sgm_step<TAIL>(NB, C, P1P1, P2P2, tail, L);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            {
+                uint4* dst = reinterpret_cast<uint4*>(&diag[par][1][lr][lic * 8]);
+                dst[0] = make_uint4(NB[0], NB[1], NB[2], NB[3]);
+                dst[1] = make_uint4(NB[4], NB[5], NB[6], NB[7]);
+            }
+            if (UP && a.naturalOut) {
+                // [A_g.lo|B_g.lo], [A_g.hi|B_g.hi]: pairs of consecutive disparities
+                u32 nat[NR];
+#pragma unroll
+                for (int g = 0; g < NR / 2; g++) {
+                    nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+                    nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                }
+                store8(sp, nat);
+            } else store8(sp, Sacc);
         }
+        __syncthreads();   // diag[par] complete before the next row reads it
     }
 }
 
@@ -370,10 +399,14 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 
 // ---------------------------------------------------------------------------------------------
 
-size_t md_sgm2_extra_bytes(int H, int W, int batch)
+static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin + pl.P2 <= 255; }
+
+size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode)
 {
     const int nstrips = (W + CW - 1) / CW;
-    return md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 6 * batch;
+    const size_t bnd = md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 4;
+    const size_t hvol = md_align((size_t)H * W * 256 * (u8mode ? 1 : 2), 256) * 2;
+    return (bnd + hvol) * batch;
 }
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
@@ -382,9 +415,11 @@ bool md_sgm2_supported(const md_sgm_plan& pl)
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 
-// S must hold H*W*256 u16 per pair; bndBase md_sgm2_extra_bytes() bytes
+bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
+
+// S must hold H*W*256 u16 per pair; extra md_sgm2_extra_bytes() bytes
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* bndBase, int batch, int naturalOut)
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut)
 {
     Sgm2Args a;
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
@@ -392,24 +427,29 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.S = S; a.strideS = strideS;
     a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD;
     a.nstrips = (pl.W + CW - 1) / CW;
+    const bool u8m = fits_u8(pl);
     const size_t oneB = md_align((size_t)pl.H * a.nstrips * 256 * sizeof(u16), 256);
-    for (int i = 0; i < 6; i++) a.bnd[i] = (u16*)(bndBase + (size_t)i * oneB * batch);
+    for (int i = 0; i < 4; i++) a.bnd[i] = (u16*)(extra + (size_t)i * oneB * batch);
     a.strideB = oneB / sizeof(u16);
+    const size_t oneH = md_align((size_t)pl.H * pl.W * 256 * (u8m ? 1 : 2), 256);
+    u8* hbase = extra + 4 * oneB * batch;
+    a.Hvol[0] = hbase; a.Hvol[1] = hbase + oneH * batch;
+    a.strideH = oneH;
     a.P1P1 = (u32)pl.P1 | ((u32)pl.P1 << 16);
     a.P2P2 = (u32)pl.P2 | ((u32)pl.P2 << 16);
     a.tail = pl.D < 256;
     a.naturalOut = naturalOut;
-    const int totalLines = 2 * pl.H + 4 * (pl.W + pl.H - 1);
-    dim3 gp((totalLines + 15) / 16, batch), gs(a.nstrips, batch);
-    if (a.tail) {
-        sgm2_prepass_kernel<true><<<gp, 256, 0, s>>>(a);
-        sgm2_sweep_kernel<false, true><<<gs, 256, 0, s>>>(a);
-        sgm2_sweep_kernel<true, true><<<gs, 256, 0, s>>>(a);
-    } else {
-        sgm2_prepass_kernel<false><<<gp, 256, 0, s>>>(a);
-        sgm2_sweep_kernel<false, false><<<gs, 256, 0, s>>>(a);
-        sgm2_sweep_kernel<true, false><<<gs, 256, 0, s>>>(a);
-    }
+    dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
+#define SGM2_LAUNCH(TAILV, U8V)                                          \
+    do {                                                                 \
+        sgm2_hscan_kernel<TAILV, U8V><<<gh, 256, 0, s>>>(a);             \
+        sgm2_prepass_kernel<TAILV><<<gp, 256, 0, s>>>(a);                \
+        sgm2_sweep_kernel<false, TAILV, U8V><<<gs, 256, 0, s>>>(a);      \
+        sgm2_sweep_kernel<true, TAILV, U8V><<<gs, 256, 0, s>>>(a);       \
+    } while (0)
+    if (a.tail) { if (u8m) SGM2_LAUNCH(true, true); else SGM2_LAUNCH(true, false); }
+    else { if (u8m) SGM2_LAUNCH(false, true); else SGM2_LAUNCH(false, false); }
+#undef SGM2_LAUNCH
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }

@@ -166,7 +166,7 @@ int mdisp_asw_gifs(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const
 int mdisp_sgbm(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out);
 
 /* The aggregated SGM cost volume S(y,x,d) = sum over paths of L_r, biased by +P2 per path (see the
- * recursion note in the README of the library sources), as uint16 [rows][cols][numDisparities] in host
+ * recursion: L'(p,d) = C + min(L'(p-r,d), L'(p-r,d+-1)+P1, min L'(p-r)+P2) - min L'(p-r)), as uint16 [rows][cols][numDisparities] in host
  * memory.  No counterpart call in the reference (StereoSGBM keeps S private); exported so that
  * the path recursion can be checked value by value. */
 int mdisp_sgbm_volume(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* S);
@@ -195,6 +195,14 @@ size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p
  * context's own workspace. */
 int mdisp_sgbm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                    const mdisp_sgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
+
+/* Batch of independent pairs in one call (one launch covers all pairs, which is what fills the
+ * GPU): pair i lives at d_left + i*pair_stride / d_right + i*pair_stride (bytes); d_disp receives
+ * batch contiguous int16 HxW maps. */
+size_t mdisp_sgbm_batch_workspace_bytes(int rows, int cols, int batch, const mdisp_sgbm_params* p);
+int mdisp_sgbm_batch_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int batch, size_t pair_stride,
+                         int rows, int cols, size_t pitch, const mdisp_sgbm_params* p, int16_t* d_disp,
+                         void* d_workspace, size_t workspace_bytes);
 
 /* census stereo on device buffers; d_disp: device double HxW */
 int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,

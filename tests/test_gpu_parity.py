@@ -129,6 +129,9 @@ SGM_CASES = [
     (16, 130, 0, 256, 8, 32, 10, 1, 8, 1),
     (12, 80, 3, 300, 10, 40, 0, 1, 8, 1),
     (3, 3, 0, 4, 0, 0, -1, 0, 8, 1),
+    (35, 49, 0, 80, 20, 300, 10, 1, 8, 1),      # path values above 255: 16-bit horizontal volumes
+    (70, 33, 1, 256, 8, 32, 10, 2, 8, 1),
+    (17, 16, 0, 32, 8, 32, 10, 1, 8, 1),
 ]
 
 
@@ -192,3 +195,37 @@ def test_remap_fixed_point(api, orc):
         o1, o2 = orc.init_undistort_rectify_map(K, dist, R, P, (60, 40))
         assert np.array_equal(m1, o1) and np.array_equal(m2, o2)
         assert np.array_equal(api.remap(img, m1, m2), orc.remap(img, m1, m2))
+
+
+def test_sgm_batch_matches_single_calls(api, orc):
+    """mdisp_sgbm_batch_dev over 3 pairs == 3 single host calls (and the oracle)."""
+    import ctypes as C
+    import torch
+    from cameracalibration_amd import _lib
+    lib = _lib.load()
+    H, W, D, B = 40, 72, 96, 3
+    params = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+    Ls, Rs = [], []
+    for i in range(B):
+        L, R, _ = api.synth_pair(0x5EED0001 + 2 * i, H, W, D)
+        Ls.append(L)
+        Rs.append(R)
+    dl = torch.from_numpy(np.stack(Ls)).cuda()
+    dr = torch.from_numpy(np.stack(Rs)).cuda()
+    out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+    ctx = _lib.Context(stream=torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.mdisp_sgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), B, H * W, H, W, W, C.byref(params),
+                                        out.data_ptr(), None, 0))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(B):
+        assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], 0, D, 8, 32, 10, 1, 8, 1))
+
+
+def test_sgm_volume_bit_exact(api, orc):
+    for (H, W, minD, D, P1, P2) in [(24, 40, 0, 16, 8, 32), (37, 53, 0, 64, 8, 32), (16, 130, 0, 256, 8, 32),
+                                    (40, 70, 3, 200, 5, 30), (33, 17, 0, 256, 8, 32), (29, 45, 0, 96, 20, 300)]:
+        L, R = rand_pair(H * 31 + W, H, W, min(D, W))
+        S = api.sgbm_volume(L, R, api.sgbm_params(minD, D, P1, P2, 10, 1, 8, 1))
+        _, E = orc.sgm(L, R, minD, D, P1, P2, 10, 1, 8, 1, want_S=True)
+        assert np.array_equal(S, E)
