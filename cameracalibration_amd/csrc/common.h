@@ -71,7 +71,7 @@ bool md_sgm2_supported(const md_sgm_plan& pl);
 size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode);
 bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* bndBase, int batch, int naturalOut);
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp);
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
                int16_t* dDisp, void* ws);

@@ -305,7 +305,10 @@ static int launch_paths(hipStream_t s, const md_sgm_plan& pl, const SgmArgs& a)
 }
 
 // dL/dR: first pair; pair i lives at +i*pairStride bytes
-static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws)
+// dDisp == nullptr: leave S8 in the S volume (natural order); otherwise the strip-fused path also
+// runs its fused winner-take-all and writes the final disparity maps.
+static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws,
+                         int16_t* dDisp)
 {
     hipStream_t s = ctx->stream;
     u8* base = (u8*)ws;
@@ -328,7 +331,8 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
     }
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
     if (pl.use_v2) {
-        rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch, 1);
+        rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch,
+                               dDisp ? 0 : 1, dDisp);
         if (rc) return rc;
     } else {
         for (int i = 0; i < pl.batch; i++) {
@@ -350,7 +354,7 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
 int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** Sout)
 {
     *Sout = (const u16*)((u8*)ws + pl.off_S);
-    return sgm_aggregate(ctx, pl, dL, dR, pitch, 0, ws);
+    return sgm_aggregate(ctx, pl, dL, dR, pitch, 0, ws, nullptr);
 }
 
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
@@ -359,7 +363,8 @@ int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR
     hipStream_t s = ctx->stream;
     u16* S = (u16*)((u8*)ws + pl.off_S);
     int rc;
-    if ((rc = sgm_aggregate(ctx, pl, dL, dR, pitch, pairStride, ws))) return rc;
+    if ((rc = sgm_aggregate(ctx, pl, dL, dR, pitch, pairStride, ws, pl.use_v2 ? dDisp : nullptr))) return rc;
+    if (pl.use_v2) return MDISP_OK;   // winner-take-all, sub-pixel and LR check ran inside the fused path
     WtaArgs w;
     w.S = S; w.sstride = pl.sstride; w.H = pl.H; w.W = pl.W; w.D = pl.D; w.minD = pl.minD;
     w.bias = pl.npaths * pl.P2; w.uniq = pl.uniq; w.maxDiff = pl.maxDiff; w.subpixel = pl.subpixel;

@@ -73,7 +73,10 @@ struct Sgm2Args {
     u32 P1P1, P2P2;
     int tail;                             // 1 when D < 256: disparities >= D are masked off
     int naturalOut;                       // up sweep: store S8 in natural d order (for the separate WTA kernel)
+    uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
+    int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
 };
+// WTA record: x = minS' | (best d << 16) | (not-unique << 31),  y = S'(best-1) | (S'(best+1) << 16)
 // order of bnd[]: 0 (1,1)  1 (-1,1)  2 (1,-1)  3 (-1,-1)
 
 // masks that pin disparities >= D of this lane to "infinite"
@@ -271,10 +274,28 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 // ---------------------------------------------------------------------------------------------
 // Main sweep.  UP = false: (0,1) (1,1) (-1,1) top to bottom, S <- H(1,0) + the three.
 //              UP = true : (0,-1) (1,-1) (-1,-1) bottom to top, S8 = S + H(-1,0) + the three.
-template <bool UP, bool TAIL, bool U8>
+template <bool UP, bool TAIL, bool U8, bool FUSE>
 __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 {
-    __shared__ u32 diag[2][2][CW][128];   // [row parity][x-1 / x+1 family][column][packed pairs]
+    // diagonal path states of the previous / current row: [row parity][x-1 / x+1 family][column][...],
+    // as packed u16 pairs (128 dwords per pixel) or, when every value fits a byte, as 64 dwords
+    constexpr int DW = U8 ? 64 : 128;
+    __shared__ u32 diag[2][2][CW][DW];
+    __shared__ u32 srow[FUSE ? CW : 1][FUSE ? 128 : 1];      // S8 of the current row, register order
+    __shared__ u32 exclMask[FUSE ? 19 : 1][NR];              // 0xFFFF over {best-1, best, best+1} by (best - lane base + 1)
+    if (FUSE) {
+        for (int i = threadIdx.x; i < 19 * NR; i += 256) {
+            const int t = i / NR, r = i % NR, rel = t - 1;
+            const int elo = 4 * (r >> 1) + (r & 1), ehi = elo + 2;
+            u32 m = 0;
+            if (t < 18) {
+                if (elo - rel >= -1 && elo - rel <= 1) m |= 0x0000FFFFu;
+                if (ehi - rel >= -1 && ehi - rel <= 1) m |= 0xFFFF0000u;
+            }
+            exclMask[t][r] = m;
+        }
+        __syncthreads();
+    }
     const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
     const int strip = blockIdx.x, pair = blockIdx.y;
     const int H = a.H, W = a.W;
@@ -348,14 +369,23 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
                     for (int q = 0; q < NR; q++) NA[q] |= tail[q];
                 }
             } else if (lr != 0) {
-                const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][0][lr - 1][lic * 8]);
-                const uint4 v0 = src[0], v1 = src[1];
-                NA[0] = v0.x; NA[1] = v0.y; NA[2] = v0.z; NA[3] = v0.w; NA[4] = v1.x; NA[5] = v1.y; NA[6] = v1.z; NA[7] = v1.w;
+                if (U8) {
+                    unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][0][lr - 1][lic * 4]), NA);
+                    if (TAIL) {   // the byte form drops the "infinite" marker of disparities >= D
+#pragma unroll
+                        for (int q = 0; q < NR; q++) NA[q] |= tail[q];
+                    }
+                } else {
+                    const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][0][lr - 1][lic * 8]);
+                    const uint4 v0 = src[0], v1 = src[1];
+                    NA[0] = v0.x; NA[1] = v0.y; NA[2] = v0.z; NA[3] = v0.w; NA[4] = v1.x; NA[5] = v1.y; NA[6] = v1.z; NA[7] = v1.w;
+                }
             }
             sgm_step<TAIL>(NA, C, P1P1, P2P2, tail, L);
 #pragma unroll
             for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            {
+            if (U8) *reinterpret_cast<uint4*>(&diag[par][0][lr][lic * 4]) = pack_bytes(NA);
+            else {
                 uint4* dst = reinterpret_cast<uint4*>(&diag[par][0][lr][lic * 8]);
                 dst[0] = make_uint4(NA[0], NA[1], NA[2], NA[3]);
                 dst[1] = make_uint4(NA[4], NA[5], NA[6], NA[7]);
@@ -368,19 +398,79 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
                     for (int q = 0; q < NR; q++) NB[q] |= tail[q];
                 }
             } else if (lr != cw - 1) {
-                const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][1][lr + 1][lic * 8]);
-                const uint4 v0 = src[0], v1 = src[1];
-                NB[0] = v0.x; NB[1] = v0.y; NB[2] = v0.z; NB[3] = v0.w; NB[4] = v1.x; NB[5] = v1.y; NB[6] = v1.z; NB[7] = v1.w;
+                if (U8) {
+                    unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][1][lr + 1][lic * 4]), NB);
+                    if (TAIL) {
+#pragma unroll
+                        for (int q = 0; q < NR; q++) NB[q] |= tail[q];
+                    }
+                } else {
+                    const uint4* src = reinterpret_cast<const uint4*>(&diag[par ^ 1][1][lr + 1][lic * 8]);
+                    const uint4 v0 = src[0], v1 = src[1];
+                    NB[0] = v0.x; NB[1] = v0.y; NB[2] = v0.z; NB[3] = v0.w; NB[4] = v1.x; NB[5] = v1.y; NB[6] = v1.z; NB[7] = v1.w;
+                }
             }
             sgm_step<TAIL>(NB, C, P1P1, P2P2, tail, L);
 #pragma unroll
             for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            {
+            if (U8) *reinterpret_cast<uint4*>(&diag[par][1][lr][lic * 4]) = pack_bytes(NB);
+            else {
                 uint4* dst = reinterpret_cast<uint4*>(&diag[par][1][lr][lic * 8]);
                 dst[0] = make_uint4(NB[0], NB[1], NB[2], NB[3]);
                 dst[1] = make_uint4(NB[4], NB[5], NB[6], NB[7]);
             }
-            if (UP && a.naturalOut) {
+            if (FUSE) {
+                // ---- winner-take-all on S8 while it is still in registers ----
+                // first minimum over d: packed keys (S << 4 | local index), then (S, d) across the 16 lanes
+                u32 kmin = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    const u32 idx = (u32)(4 * (q >> 1) + (q & 1)) | ((u32)(4 * (q >> 1) + (q & 1) + 2) << 16);
+                    u32 k = asu(asv(Sacc[q]) * (unsigned short)16 + asv(idx));
+                    if (TAIL) k |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+                    kmin = q == 0 ? k : pkmin(kmin, k);
+                }
+                const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
+                u32 key = ((kl >> 4) << 16) | (u32)(lic * DPL) | (kl & 15u);
+                key = row_min16(key);
+                const int best = (int)(key & 0xFFFFu);
+                const int minS = (int)(key >> 16);
+                // smallest S outside {best-1, best, best+1}
+                const int rel = best - lic * DPL;
+                const int tsel = (unsigned)(rel + 1) <= 17u ? rel + 1 : 18;
+                const uint4 m0 = *reinterpret_cast<const uint4*>(&exclMask[tsel][0]);
+                const uint4 m1 = *reinterpret_cast<const uint4*>(&exclMask[tsel][4]);
+                const u32 em[NR] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                u32 smin = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    u32 v = Sacc[q] | em[q];
+                    if (TAIL) v |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+                    smin = q == 0 ? v : pkmin(smin, v);
+                }
+                const int mex = (int)row_min16(min(smin & 0xFFFFu, smin >> 16));
+                // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
+                const bool notUnique = mex != 0xFFFF && (mex - a.bias) * (100 - a.uniq) < (minS - a.bias) * 100;
+                // neighbours of the minimum for the parabola fit, through LDS (register order)
+                {
+                    uint4* dst = reinterpret_cast<uint4*>(&srow[lr][lic * 8]);
+                    dst[0] = make_uint4(Sacc[0], Sacc[1], Sacc[2], Sacc[3]);
+                    dst[1] = make_uint4(Sacc[4], Sacc[5], Sacc[6], Sacc[7]);
+                }
+                auto s_at = [&](int d) -> u32 {
+                    d = min(max(d, 0), 255);
+                    const int e = d & 15;
+                    const int reg = 2 * (e >> 2) + (e & 1), half = (e >> 1) & 1;
+                    return (srow[lr][(d >> 4) * 8 + reg] >> (16 * half)) & 0xFFFFu;
+                };
+                const u32 sm = s_at(best - 1), spl = s_at(best + 1);
+                if (lic == 0) {
+                    uint2 rec;
+                    rec.x = (u32)minS | ((u32)best << 16) | (notUnique ? 0x80000000u : 0u);
+                    rec.y = sm | (spl << 16);
+                    a.rec[(size_t)pair * a.strideRec + (size_t)y * W + x] = rec;
+                }
+            } else if (UP && a.naturalOut) {
                 // [A_g.lo|B_g.lo], [A_g.hi|B_g.hi]: pairs of consecutive disparities
                 u32 nat[NR];
 #pragma unroll
@@ -395,6 +485,61 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     }
 }
 
+struct LrArgs {
+    const uint2* rec; size_t strideRec;
+    int H, W, D, minD, maxDiff, subpixel;
+    int16_t* disp; size_t strideDisp;
+};
+
+// One workgroup per image row: sub-pixel parabola, disp2 slot election (minimum S, ties to the
+// larger x: StereoSGBM walks x right to left with a strict '>' test) by a packed atomicMin in
+// LDS, then the disp12MaxDiff check.
+__global__ __launch_bounds__(256) void sgm2_lr_kernel(LrArgs a)
+{
+    extern __shared__ u32 lds[];
+    u32* key = lds;                                          // [W] (S'min << 16) | (0xFFFF - x)
+    int16_t* d1 = reinterpret_cast<int16_t*>(lds + a.W);     // [W]
+    const int y = blockIdx.x, W = a.W, D = a.D;
+    const int INVALID = (a.minD - 1) * 16;
+    const uint2* rrow = a.rec + (size_t)blockIdx.y * a.strideRec + (size_t)y * W;
+    int16_t* drow = a.disp + (size_t)blockIdx.y * a.strideDisp + (size_t)y * W;
+    for (int i = threadIdx.x; i < W; i += 256) key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const uint2 r = rrow[x];
+        int v = INVALID;
+        if (!(r.x & 0x80000000u)) {
+            const int minS = (int)(r.x & 0xFFFFu);
+            int d = (int)((r.x >> 16) & 0x7FFFu);
+            const int x2 = x - d - a.minD;
+            if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((u32)minS << 16) | (u32)(0xFFFF - x));
+            if (a.subpixel && d > 0 && d < D - 1) {
+                const int sm = (int)(r.y & 0xFFFFu), spl = (int)(r.y >> 16);
+                int den = sm + spl - 2 * minS;
+                if (den < 1) den = 1;
+                d = d * 16 + ((sm - spl) * 16 + den) / (den * 2);
+            } else d *= 16;
+            v = d + a.minD * 16;
+        }
+        d1[x] = (int16_t)v;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int v = d1[x];
+        if (v != INVALID) {
+            auto inconsistent = [&](int xx, int dd) -> bool {
+                if (xx < 0 || xx >= W) return false;
+                const u32 kk = key[xx];
+                const int d2 = (kk == 0xFFFFFFFFu) ? INVALID : (0xFFFF - (int)(kk & 0xFFFF)) - xx;
+                return d2 >= a.minD && abs(d2 - dd) > a.maxDiff;
+            };
+            const int _d = v >> 4, d_ = (v + 15) >> 4;
+            if (inconsistent(x - _d, _d) && inconsistent(x - d_, d_)) v = INVALID;
+        }
+        drow[x] = (int16_t)v;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -406,7 +551,8 @@ size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode)
     const int nstrips = (W + CW - 1) / CW;
     const size_t bnd = md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 4;
     const size_t hvol = md_align((size_t)H * W * 256 * (u8mode ? 1 : 2), 256) * 2;
-    return (bnd + hvol) * batch;
+    const size_t rec = md_align((size_t)H * W * sizeof(uint2), 256);
+    return (bnd + hvol + rec) * batch;
 }
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
@@ -418,8 +564,10 @@ bool md_sgm2_supported(const md_sgm_plan& pl)
 bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
 
 // S must hold H*W*256 u16 per pair; extra md_sgm2_extra_bytes() bytes
+// naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
+// naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut)
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp)
 {
     Sgm2Args a;
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
@@ -439,17 +587,29 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.P2P2 = (u32)pl.P2 | ((u32)pl.P2 << 16);
     a.tail = pl.D < 256;
     a.naturalOut = naturalOut;
+    const size_t oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
+    a.rec = (uint2*)(hbase + 2 * oneH * batch);
+    a.strideRec = oneRec / sizeof(uint2);
+    a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
     do {                                                                 \
         sgm2_hscan_kernel<TAILV, U8V><<<gh, 256, 0, s>>>(a);             \
         sgm2_prepass_kernel<TAILV><<<gp, 256, 0, s>>>(a);                \
-        sgm2_sweep_kernel<false, TAILV, U8V><<<gs, 256, 0, s>>>(a);      \
-        sgm2_sweep_kernel<true, TAILV, U8V><<<gs, 256, 0, s>>>(a);       \
+        sgm2_sweep_kernel<false, TAILV, U8V, false><<<gs, 256, 0, s>>>(a);                           \
+        if (naturalOut) sgm2_sweep_kernel<true, TAILV, U8V, false><<<gs, 256, 0, s>>>(a);            \
+        else sgm2_sweep_kernel<true, TAILV, U8V, true><<<gs, 256, 0, s>>>(a);                        \
     } while (0)
     if (a.tail) { if (u8m) SGM2_LAUNCH(true, true); else SGM2_LAUNCH(true, false); }
     else { if (u8m) SGM2_LAUNCH(false, true); else SGM2_LAUNCH(false, false); }
 #undef SGM2_LAUNCH
     MD_HIP(hipGetLastError());
+    if (!naturalOut) {
+        LrArgs l;
+        l.rec = a.rec; l.strideRec = a.strideRec; l.H = pl.H; l.W = pl.W; l.D = pl.D; l.minD = pl.minD;
+        l.maxDiff = pl.maxDiff; l.subpixel = pl.subpixel; l.disp = dDisp; l.strideDisp = (size_t)pl.H * pl.W;
+        sgm2_lr_kernel<<<dim3(pl.H, batch), 256, (size_t)pl.W * 6 + 16, s>>>(l);
+        MD_HIP(hipGetLastError());
+    }
     return MDISP_OK;
 }
