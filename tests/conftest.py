@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+# torch carries its own HIP runtime: it has to be loaded before libmdisp.so pulls in the system one,
+# otherwise torch.cuda finds no devices in the tests that use torch for device buffers.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
