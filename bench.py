@@ -43,6 +43,17 @@ def cpu_baseline(orc, api):
             "sample": f"{frames} frame(s) of {W}x{H}, D={D}, SGM 8-path + LR + subpixel, {dt:.1f} s of CPU work"}
 
 
+def measured_traffic():
+    """HBM bytes per pair from the committed rocprofv3 PMC passes of this command (FETCH_SIZE and
+    WRITE_SIZE need separate runs, so they cannot be collected inside a timed run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return float(json.load(f)["traffic_bytes_per_pair"]), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +138,7 @@ def main():
     achieved = alg_bytes / pair_s / 1e9
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "Mdisp/s (WxHxD per sec) at 1920x1080, D=256",
             "value": total_units / elapsed / 1e6,
@@ -143,8 +155,9 @@ def main():
             "config": {"workload": "1920x1080 D=256 census-Hamming cost + SGM 8-path + WTA/uniqueness + x16 subpixel + LR check",
                        "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "all launches of one batch call (census, border pre-pass, down sweep, up sweep, WTA)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "all launches of one batch call, per pair (census, horizontal scan, border pre-pass, "
+                                   "down sweep, up sweep + WTA, LR/sub-pixel)",
                          "ms_per_pair": pair_s * 1e3, "ms_aggregation_per_pair": float(np.mean(agg_ms)) / B,
                          "algorithmic_bytes_per_pair": alg_bytes},
         }
