@@ -50,5 +50,20 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_host_test():
+    """Compile the C++ host-layer exerciser (tests/cpp/host_mirror.cpp) against libmdisp.so with g++."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "host_mirror.cpp")
+    out = os.path.join(root, "tests", "cpp", "_build", "host_mirror")
+    deps = [src, os.path.join(root, "include", "mdisp_host.hpp"), os.path.join(root, "include", "mdisp.h"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", out,
+                           "-L" + os.path.dirname(LIB), "-lmdisp", "-Wl,-rpath,$ORIGIN/../../../cameracalibration_amd/lib"])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host_test())

@@ -37,7 +37,7 @@ struct mdisp_ctx {
     void* ws;            // grow-only device workspace
     size_t ws_bytes;
     bool timing;
-    hipEvent_t ev[6];    // [0,1] whole call, [2,3] SGM down sweep, [4,5] SGM up sweep
+    hipEvent_t ev[6];    // [0,1] whole call, [2,3] SGM aggregation, [4,5] separate WTA kernel
     bool ev_valid[3];
 };
 

@@ -209,7 +209,9 @@ int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_
                             const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
 
 /* time of the most recent call's dominant kernel on this context, measured with HIP events on
- * the context's stream (milliseconds); which = 0: whole call, 1: SGM down sweep, 2: SGM up sweep */
+ * the context's stream (milliseconds); which = 0: whole call, 1: SGM path aggregation (every scan
+ * and sweep kernel of the call), 2: the separate winner-take-all kernel of the per-direction
+ * fallback (not recorded when winner-take-all is fused into the upward sweep) */
 int mdisp_last_kernel_ms(mdisp_ctx*, int which, float* ms);
 int mdisp_enable_timing(mdisp_ctx*, int on);
 

@@ -1,0 +1,277 @@
+// C++ host layer over the C ABI of libmdisp.so: the reference's function-level stereo API
+// (cameraCalibration/disp_method/methods_disp.h, gifs.h, steerFilter.h, methods/methods.h) with the
+// image type left as a template parameter, so the same code serves cv::Mat (see mdisp_cv.hpp) and
+// the small self-contained mdisp::Mat below (used where OpenCV is not installed).
+//
+// Behaviour kept from the reference:
+//   - parameters are passed by value, outputs are freshly allocated images owned by the caller;
+//   - on bad parameters (empty image, size mismatch, even winSize) a message goes to std::cout and an
+//     EMPTY image is returned (methods_disp.cpp:209-215, 313-319, 847-853, 1149-1155);
+//   - StereoMatchParam::maxDisparity is inclusive (methods_disp.cpp:219).
+// Failures of the GPU runtime (no device, HIP error) are not part of the reference's vocabulary:
+// they throw mdisp::Error.  There is no CPU fallback.
+#ifndef MDISP_HOST_HPP
+#define MDISP_HOST_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mdisp.h"
+
+namespace mdisp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error("mdisp error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+// ---- a minimal reference-counted image with cv::Mat's value semantics ------------------------
+class Mat {
+public:
+    int rows = 0, cols = 0, channels = 1, depth = MDISP_8U;
+    size_t step = 0;
+    Mat() = default;
+    Mat(int r, int c, int depth_, int ch = 1) { create(r, c, depth_, ch); }
+    void create(int r, int c, int depth_, int ch = 1)
+    {
+        static const int esz[7] = {1, 1, 2, 2, 4, 4, 8};
+        rows = r; cols = c; depth = depth_; channels = ch;
+        step = (size_t)c * ch * esz[depth_];
+        buf_ = std::make_shared<std::vector<uint8_t>>(step * (size_t)r);
+    }
+    bool empty() const { return !buf_ || rows == 0 || cols == 0; }
+    uint8_t* data() { return buf_ ? buf_->data() : nullptr; }
+    const uint8_t* data() const { return buf_ ? buf_->data() : nullptr; }
+    template <class T> T* ptr(int y) { return reinterpret_cast<T*>(data() + step * (size_t)y); }
+    template <class T> const T* ptr(int y) const { return reinterpret_cast<const T*>(data() + step * (size_t)y); }
+    template <class T> T& at(int y, int x) { return ptr<T>(y)[x]; }
+    template <class T> const T& at(int y, int x) const { return ptr<T>(y)[x]; }
+
+private:
+    std::shared_ptr<std::vector<uint8_t>> buf_;
+};
+
+// ---- how the layer looks at an image type ------------------------------------------------------
+template <class M> struct mat_traits;
+template <> struct mat_traits<Mat> {
+    static bool empty(const Mat& m) { return m.empty(); }
+    static mdisp_image view(const Mat& m)
+    {
+        mdisp_image v;
+        v.data = const_cast<uint8_t*>(m.data()); v.rows = m.rows; v.cols = m.cols; v.channels = m.channels;
+        v.depth = m.depth; v.step_bytes = m.step;
+        return v;
+    }
+    static void create(Mat& m, int rows, int cols, int depth, int channels) { m.create(rows, cols, depth, channels); }
+};
+
+// ---- enums of the reference, same enumerators and values --------------------------------------
+enum CENSUS_ALGORITHM {   // methods_disp.h:18-27
+    BASIC_CENSUS = MDISP_BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS,
+    STATISTIC_MULTISCALE_CENSUS, CENSUS_2017
+};
+enum GIF_TYPE { GIF = MDISP_GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 };   // gifs.h:4-13; OURS_* are rejected as unsupported
+
+// StereoMatchParam, methods_disp.h:5-16
+template <class M> struct StereoMatchParamT {
+    M imgLeft, imgRight, imgLeft_C, imgRight_C;
+    int winSize = 7;
+    int minDisparity = 0;
+    int maxDisparity = 30;
+    bool isDispLeft = true;
+};
+
+// ---- one context per host thread (the reference runs its L and R calls on two std::async threads)
+class Context {
+public:
+    explicit Context(int device = -1, void* stream = nullptr)
+    {
+        int rc = mdisp_create(&h_, device, stream);
+        if (rc) throw Error(rc, mdisp_last_error());
+    }
+    ~Context() { if (h_) mdisp_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    mdisp_ctx* handle() const { return h_; }
+    static Context& forThisThread()
+    {
+        thread_local Context c;
+        return c;
+    }
+
+private:
+    mdisp_ctx* h_ = nullptr;
+};
+
+namespace detail {
+inline void bad_parameters() { std::cout << "bad function parameters, please check image and window size." << std::endl; }
+inline void check(int rc) { if (rc) throw Error(rc, mdisp_last_error()); }
+
+template <class M, class F> M pair_call(const StereoMatchParamT<M>& p, int outDepth, F&& fn)
+{
+    typedef mat_traits<M> T;
+    if (T::empty(p.imgLeft) || T::empty(p.imgRight)) {
+        std::cout << "empty image error" << std::endl;
+        bad_parameters();
+        return M();
+    }
+    mdisp_image l = T::view(p.imgLeft), r = T::view(p.imgRight);
+    mdisp_param pod = {p.winSize, p.minDisparity, p.maxDisparity, p.isDispLeft ? 1 : 0};
+    M out;
+    T::create(out, l.rows, l.cols, outDepth, 1);
+    mdisp_image o = T::view(out);
+    int rc = fn(Context::forThisThread().handle(), &l, &r, &pod, &o);
+    if (rc == MDISP_E_BADARG) { bad_parameters(); return M(); }
+    check(rc);
+    return out;
+}
+}  // namespace detail
+
+// methods_disp.h:43-44  -> CV_8U disparity
+template <class M> M computeSAD_inteOpti(StereoMatchParamT<M> param)
+{ return detail::pair_call(param, MDISP_8U, mdisp_sad_inte); }
+template <class M> M computeSAD_BFOpti(StereoMatchParamT<M> param)
+{ return detail::pair_call(param, MDISP_8U, mdisp_sad_box); }
+
+// methods_disp.h:62 -> CV_64F disparity.  The reference aggregates every Hamming slice with
+// getGuidedFilter(img, slice, winSize, 1e-6) (methods_disp.cpp:978) = MDISP_AGG_GUIDED.
+template <class M> M censusStereo(StereoMatchParamT<M> param, CENSUS_ALGORITHM method = BASIC_CENSUS, int agg = MDISP_AGG_GUIDED)
+{
+    return detail::pair_call(param, MDISP_64F, [&](mdisp_ctx* c, const mdisp_image* l, const mdisp_image* r, const mdisp_param* p,
+                                                   mdisp_image* o) { return mdisp_census_stereo(c, l, r, p, (int)method, agg, o); });
+}
+
+// methods_disp.h:66 -> CV_32F disparity.  cost_source selects what stands in for the dense-SIFT
+// slices of computeDisp_Feature; with MDISP_COST_VOLUME the caller passes those slices.
+template <class M> M asw_gifs(StereoMatchParamT<M> param, double eps, GIF_TYPE gifType = GIF, int r2 = 5, double namda = 0.1,
+                              double h = 0.5, int cost_source = MDISP_COST_CENSUS, const float* costs = nullptr)
+{
+    return detail::pair_call(param, MDISP_32F, [&](mdisp_ctx* c, const mdisp_image* l, const mdisp_image* r, const mdisp_param* p,
+                                                   mdisp_image* o) {
+        return mdisp_asw_gifs(c, l, r, p, eps, (int)gifType, r2, namda, h, cost_source, costs, o);
+    });
+}
+
+// countCensusImg* (methods_disp.h:46-58): dst is allocated here
+template <class M> void countCensusImg(M src, M& dst, CENSUS_ALGORITHM method = BASIC_CENSUS, int arg = 0)
+{
+    typedef mat_traits<M> T;
+    mdisp_image s = T::view(src);
+    T::create(dst, s.rows, s.cols, MDISP_8U, 1);
+    mdisp_image d = T::view(dst);
+    detail::check(mdisp_census_transform(Context::forThisThread().handle(), &s, (int)method, arg, &d));
+}
+template <class M> void countCensusImg_rotationInv(M src, M& dst) { countCensusImg(src, dst, ROTATION_INVARIANT_CENSUS); }
+template <class M> void countCensusImg_uniform(M src, M& dst) { countCensusImg(src, dst, UNIFORM_CENSUS); }
+template <class M> void countCensusImg_multiScale(M src, M& dst, int scale) { countCensusImg(src, dst, MULTISCALE_CENSUS, scale); }
+template <class M> void countCensusImg_circle(M src, M& dst, int radius, int samplePtNum = 8)
+{
+    if (samplePtNum != 8) throw Error(MDISP_E_UNSUPPORTED, "countCensusImg_circle: only 8 sample points are built");
+    countCensusImg(src, dst, CIRCLE_CENSUS, radius);
+}
+
+// countHummingDist (methods_disp.h:60): CV_32S popcount(a ^ b)
+template <class M> void countHummingDist(M src1, M src2, M& dst)
+{
+    typedef mat_traits<M> T;
+    mdisp_image a = T::view(src1), b = T::view(src2);
+    T::create(dst, a.rows, a.cols, MDISP_32S, 1);
+    mdisp_image d = T::view(dst);
+    detail::check(mdisp_hamming_dist(Context::forThisThread().handle(), &a, &b, &d));
+}
+
+// gifs.h:17-33
+template <class M> M guidedFilter_(M guide, M P, int r, double eps, int type, const M* steerW, int r2, double namuda, M* beta)
+{
+    typedef mat_traits<M> T;
+    mdisp_image g = T::view(guide), p = T::view(P), sw, bv;
+    M out;
+    T::create(out, g.rows, g.cols, MDISP_32F, 1);
+    mdisp_image o = T::view(out);
+    if (steerW) sw = T::view(*steerW);
+    if (beta) { T::create(*beta, g.rows, g.cols, MDISP_32F, 1); bv = T::view(*beta); }
+    detail::check(mdisp_guided_filter(Context::forThisThread().handle(), &g, &p, r, eps, type, steerW ? &sw : nullptr, r2, namuda, &o,
+                                      beta ? &bv : nullptr));
+    return out;
+}
+template <class M> M getGuidedFilter(M guidedImg, M inputP, int r, double eps)
+{ return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_GIF, nullptr, 0, 0.0, nullptr); }
+template <class M> M getGuidedFilter_wgif(M guidedImg, M inputP, int r, double eps)
+{ return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_WGIF, nullptr, 0, 0.0, nullptr); }
+template <class M> M getGuidedFilter_egif(M guidedImg, M inputP, int r, double eps, M& beta)
+{ return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_EGIF, nullptr, 0, 0.0, &beta); }
+template <class M> M getGuidedFilter_skwgif2(M guidedImg, M inputP, M steerFilterW, int r, int r2, double eps, double namuda, double h = 0.5)
+{ (void)h; return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_SKWGIF, &steerFilterW, r2, namuda, nullptr); }
+
+// steerFilter.h:39 -> CV_64F
+template <class M> void steerFilter(M src, M& dst)
+{
+    typedef mat_traits<M> T;
+    mdisp_image s = T::view(src);
+    T::create(dst, s.rows, s.cols, MDISP_64F, 1);
+    mdisp_image d = T::view(dst);
+    detail::check(mdisp_steer_filter(Context::forThisThread().handle(), &s, &d));
+}
+
+// cv::StereoSGBM::compute stand-in -> CV_16S x16 (the census-Hamming cost replaces Birchfield-Tomasi)
+template <class M> void sgbmCompute(M left, M right, const mdisp_sgbm_params& p, M& disp16)
+{
+    typedef mat_traits<M> T;
+    mdisp_image l = T::view(left), r = T::view(right);
+    T::create(disp16, l.rows, l.cols, MDISP_16S, 1);
+    mdisp_image d = T::view(disp16);
+    detail::check(mdisp_sgbm(Context::forThisThread().handle(), &l, &r, &p, &d));
+}
+
+// methods/methods.h:33, methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7), compute, disp / 16
+// (CV_16S MatExpr divide: round to nearest, ties to even)
+template <class M> void getDisparity_SGBM(M srcLeft, M srcRight, M& disparityMap)
+{
+    typedef mat_traits<M> T;
+    if (T::empty(srcLeft) || T::empty(srcRight)) { std::cout << " --(!) Error reading images " << std::endl; return; }
+    mdisp_sgbm_params p = {0, 48, 0, 0, -1, 0, 5, 1, 1, MDISP_BASIC_CENSUS};
+    sgbmCompute(srcLeft, srcRight, p, disparityMap);
+    mdisp_image d = T::view(disparityMap);
+    for (int y = 0; y < d.rows; y++) {
+        int16_t* row = reinterpret_cast<int16_t*>(static_cast<uint8_t*>(d.data) + d.step_bytes * (size_t)y);
+        for (int x = 0; x < d.cols; x++) {
+            const int v = row[x], q = v >> 4, rem = v & 15;          // floor division by 16
+            row[x] = (int16_t)(q + (rem > 8 || (rem == 8 && (q & 1))));
+        }
+    }
+}
+
+// PatchMatch::postProcess validity test, methods/patchmatch.cpp:817-828
+template <class M> void lrCheck(M dispL, M dispR, float thresh, M& validL, M& validR)
+{
+    typedef mat_traits<M> T;
+    mdisp_image a = T::view(dispL), b = T::view(dispR);
+    T::create(validL, a.rows, a.cols, MDISP_8U, 1);
+    T::create(validR, a.rows, a.cols, MDISP_8U, 1);
+    mdisp_image vl = T::view(validL), vr = T::view(validR);
+    detail::check(mdisp_lr_check(Context::forThisThread().handle(), &a, &b, thresh, &vl, &vr));
+}
+
+// the rectification step of getRectifiedImages (methods/methods.cpp:1705-1745): maps on the host in
+// double precision, remap on the GPU.  K, dist, R, P are row-major.
+template <class M> void rectifyImage(M src, const double K[9], const double* dist, int ndist, const double R[9], const double P[12], M& dst)
+{
+    typedef mat_traits<M> T;
+    mdisp_image s = T::view(src);
+    std::vector<int16_t> m1((size_t)s.rows * s.cols * 2);
+    std::vector<uint16_t> m2((size_t)s.rows * s.cols);
+    detail::check(mdisp_build_rectify_maps(K, dist, ndist, R, P, s.cols, s.rows, m1.data(), m2.data()));
+    T::create(dst, s.rows, s.cols, MDISP_8U, s.channels);
+    mdisp_image d = T::view(dst);
+    detail::check(mdisp_remap(Context::forThisThread().handle(), &s, m1.data(), m2.data(), &d));
+}
+
+typedef StereoMatchParamT<Mat> StereoMatchParam;
+
+}  // namespace mdisp
+#endif  // MDISP_HOST_HPP

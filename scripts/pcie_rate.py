@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Rate of the host-buffer entry point (mdisp_sgbm: H2D copies + kernels + D2H copy) at 1920x1080, D=256,
+for comparison with the HBM-resident rate bench.py reports."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cameracalibration_amd import api  # noqa: E402
+
+H, W, D = 1080, 1920, 256
+L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+p = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+api.sgbm_compute(L, R, p)
+n = 10
+t0 = time.perf_counter()
+for _ in range(n):
+    api.sgbm_compute(L, R, p)
+dt = (time.perf_counter() - t0) / n
+print(f"host-buffer mdisp_sgbm: {dt*1e3:.2f} ms per pair, {H*W*D/dt/1e6:.0f} Mdisp/s (PCIe copies and sync included)")

@@ -1,0 +1,56 @@
+// Exercises the C++ host layer (include/mdisp_host.hpp) with its built-in image type.
+//   host_mirror              : error behaviour only (no GPU needed)
+//   host_mirror gpu <H> <W> <maxD> <out.bin> : runs censusStereo, SAD and SGBM on a synthetic pair
+//                              and dumps the outputs for comparison against the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "mdisp_host.hpp"
+
+using namespace mdisp;
+
+static int fail(const char* what) { std::printf("FAIL: %s\n", what); return 1; }
+
+int main(int argc, char** argv)
+{
+    // --- reference error behaviour: message + empty image, nothing thrown
+    {
+        StereoMatchParam p;          // empty images
+        Mat d;
+        try { d = computeSAD_BFOpti(p); } catch (...) { return fail("empty input must not throw"); }
+        if (!d.empty()) return fail("empty input must give an empty image");
+        d = censusStereo(p, BASIC_CENSUS);
+        if (!d.empty()) return fail("censusStereo on empty input must give an empty image");
+    }
+    if (argc < 6 || std::strcmp(argv[1], "gpu") != 0) { std::printf("OK (no-GPU checks)\n"); return 0; }
+
+    const int H = std::atoi(argv[2]), W = std::atoi(argv[3]), maxD = std::atoi(argv[4]);
+    Mat L(H, W, MDISP_8U), R(H, W, MDISP_8U);
+    if (mdisp_synth_pair(0x5EED0001u, H, W, maxD + 1, L.data(), R.data(), nullptr)) return fail("synth");
+    StereoMatchParam p;
+    p.imgLeft = L; p.imgRight = R; p.winSize = 7; p.minDisparity = 0; p.maxDisparity = maxD; p.isDispLeft = true;
+    {   // even window: message + empty image
+        StereoMatchParam q = p; q.winSize = 6;
+        if (!computeSAD_inteOpti(q).empty()) return fail("even winSize must give an empty image");
+    }
+    Mat dCensus = censusStereo(p, BASIC_CENSUS, MDISP_AGG_BOX);   // CV_64F
+    Mat dSad = computeSAD_BFOpti(p);                               // CV_8U
+    Mat d16;
+    mdisp_sgbm_params sp = {0, maxD + 1, 8, 32, 10, 1, 8, 1, 1, MDISP_BASIC_CENSUS};
+    sgbmCompute(L, R, sp, d16);                                    // CV_16S
+    Mat cen;
+    countCensusImg(L, cen);
+    if (dCensus.empty() || dSad.empty() || d16.empty() || cen.empty()) return fail("empty output");
+    FILE* f = std::fopen(argv[5], "wb");
+    if (!f) return fail("open output");
+    std::fwrite(L.data(), 1, (size_t)H * W, f);
+    std::fwrite(R.data(), 1, (size_t)H * W, f);
+    std::fwrite(dCensus.data(), 8, (size_t)H * W, f);
+    std::fwrite(dSad.data(), 1, (size_t)H * W, f);
+    std::fwrite(d16.data(), 2, (size_t)H * W, f);
+    std::fwrite(cen.data(), 1, (size_t)H * W, f);
+    std::fclose(f);
+    std::printf("OK\n");
+    return 0;
+}

@@ -1,0 +1,55 @@
+"""The C++ host layer (include/mdisp_host.hpp): reference error behaviour on the CPU, and on the GPU
+its outputs against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "_build", "host_mirror")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        from cameracalibration_amd import build
+        build.build_host_test()
+    return EXE
+
+
+def test_host_layer_error_behaviour_matches_reference():
+    # empty input: the reference prints its message and returns an empty Mat (methods_disp.cpp:209-215)
+    r = subprocess.run([_exe()], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad function parameters, please check image and window size." in r.stdout
+    assert "OK (no-GPU checks)" in r.stdout
+
+
+def test_cv_adapter_names_every_boundary_function():
+    # the OpenCV adapter cannot be compiled here (no OpenCV); check that it declares the reference's names
+    text = open(os.path.join(ROOT, "include", "mdisp_cv.hpp")).read()
+    for name in ("computeSAD_inteOpti", "computeSAD_BFOpti", "censusStereo", "asw_gifs", "countCensusImg", "countHummingDist",
+                 "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "steerFilter",
+                 "getDisparity_SGBM", "StereoMatchParam"):
+        assert name in text
+
+
+@pytest.mark.gpu
+def test_host_layer_outputs_match_oracle(orc, tmp_path):
+    H, W, maxD = 72, 120, 31
+    out = tmp_path / "host.bin"
+    r = subprocess.run([_exe(), "gpu", str(H), str(W), str(maxD), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = np.fromfile(out, dtype=np.uint8)
+    n = H * W
+    o = 0
+    L = buf[o:o + n].reshape(H, W); o += n
+    R = buf[o:o + n].reshape(H, W); o += n
+    dC = buf[o:o + 8 * n].view(np.float64).reshape(H, W); o += 8 * n
+    dS = buf[o:o + n].reshape(H, W); o += n
+    d16 = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
+    cen = buf[o:o + n].reshape(H, W)
+    assert np.array_equal(dC, orc.census_stereo(L, R, 7, 0, maxD, True, orc.BASIC_CENSUS, orc.AGG_BOX))
+    assert np.array_equal(dS, orc.sad_box(L, R, 7, 0, maxD, True))
+    assert np.array_equal(d16, orc.sgm(L, R, 0, maxD + 1, 8, 32, 10, 1, 8, 1))
+    assert np.array_equal(cen, orc.census(L, orc.BASIC_CENSUS, 0))
