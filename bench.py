@@ -76,7 +76,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from cameracalibration_amd import _lib, api
+    from cameracalibration_amd import _lib, api, shard
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
     ctx = _lib.Context(device=local_rank, stream=stream)
@@ -86,8 +86,10 @@ def main():
     B = args.pairs
     lefts = torch.empty((B, H, W), dtype=torch.uint8)
     rights = torch.empty((B, H, W), dtype=torch.uint8)
+    first, count = shard.pair_block(B * world, rank, world)     # weak scaling: B pairs per rank
+    assert count == B
     for i in range(B):
-        L, R, _ = api.synth_pair(0x5EED0001 + 2 * (rank * B + i), H, W, D)
+        L, R, _ = api.synth_pair(shard.pair_seed(first + i), H, W, D)
         lefts[i] = torch.from_numpy(L)
         rights[i] = torch.from_numpy(R)
     lefts, rights = lefts.cuda(), rights.cuda()
@@ -113,10 +115,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.slowest_rank_seconds(elapsed, dist if world > 1 else None, device="cuda")
 
     # per-pair device time of the hot path, HIP events on the stream the kernels run on
     _lib.check(lib.mdisp_enable_timing(ctx.handle, 1))
@@ -141,7 +140,7 @@ def main():
         traffic, traffic_src = measured_traffic()
         out = {
             "metric": "Mdisp/s (WxHxD per sec) at 1920x1080, D=256",
-            "value": total_units / elapsed / 1e6,
+            "value": shard.job_throughput(units_per_pair, args.pairs * args.steps * world, elapsed),
             "unit": "Mdisp/s",
             "n_gpus": world,
             "steps": args.steps,

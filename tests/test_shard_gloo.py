@@ -1,0 +1,70 @@
+"""Pair sharding across ranks, exercised with two gloo processes on the CPU (the same code path
+bench.py runs over RCCL with one process per GPU)."""
+import os
+import socket
+import sys
+
+import pytest
+
+from cameracalibration_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_blocks_cover_every_pair_once():
+    for total in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                first, count = shard.pair_block(total, r, world)
+                seen.extend(range(first, first + count))
+            assert seen == list(range(total))
+            counts = [shard.pair_block(total, r, world)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        shard.pair_block(4, 2, 2)
+
+
+def test_seeds_are_distinct_per_pair():
+    assert len({shard.pair_seed(i) for i in range(512)}) == 512
+    assert shard.pair_seed(0) == 0x5EED0001 and shard.pair_seed(1) == 0x5EED0003
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = 13
+        first, count = shard.pair_block(total, rank, world)
+        mine = torch.zeros(total, dtype=torch.int32)
+        mine[first:first + count] = 1
+        dist.all_reduce(mine)                       # test-only collective: every pair owned exactly once
+        slow = shard.slowest_rank_seconds(1.0 + rank, dist)
+        dist.barrier()
+        q.put((rank, bool((mine == 1).all()), slow, count))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert [r[2] for r in res] == [2.0, 2.0]        # both ranks see the slowest rank's time
+    assert sum(r[3] for r in res) == 13
+    assert shard.job_throughput(1920 * 1080 * 256, 13, 2.0) == pytest.approx(1920 * 1080 * 256 * 13 / 2.0 / 1e6)
