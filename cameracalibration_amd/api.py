@@ -252,6 +252,25 @@ def initUndistortRectifyMap(K, dist, R, P, size):
     return m1, m2
 
 
+def stereoRectify(K1, D1, K2, D2, size, R, T, zero_disparity=True, alpha=-1.0):
+    """cv::stereoRectify as called at methods/methods.cpp:1691-1694 (newImageSize = imageSize).
+    Returns (R1, R2, P1, P2, Q, roi1, roi2)."""
+    W, H = size
+    dp = C.POINTER(C.c_double)
+    f = lambda a, n: np.ascontiguousarray(a, dtype=np.float64).reshape(n)  # noqa: E731
+    K1, K2, R, T = f(K1, 9), f(K2, 9), f(R, 9), f(T, 3)
+    D1 = np.ascontiguousarray(D1, dtype=np.float64).reshape(-1)
+    D2 = np.ascontiguousarray(D2, dtype=np.float64).reshape(-1)
+    if D1.size != D2.size:
+        raise ValueError("distortion vectors must have the same length")
+    R1, R2, P1, P2, Q = (np.empty(n, dtype=np.float64) for n in (9, 9, 12, 12, 16))
+    roi1, roi2 = (C.c_int * 4)(), (C.c_int * 4)()
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    check(load().mdisp_stereo_rectify(p(K1), p(D1), p(K2), p(D2), D1.size, W, H, p(R), p(T), 1 if zero_disparity else 0,
+                                      float(alpha), p(R1), p(R2), p(P1), p(P2), p(Q), roi1, roi2))
+    return R1.reshape(3, 3), R2.reshape(3, 3), P1.reshape(3, 4), P2.reshape(3, 4), Q.reshape(4, 4), tuple(roi1), tuple(roi2)
+
+
 def remap(src, map1, map2, ctx=None):
     """cv::remap(src, dst, map1, map2, INTER_LINEAR), constant-0 border."""
     src = _u8(src)

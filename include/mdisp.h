@@ -181,6 +181,17 @@ int mdisp_lr_check(mdisp_ctx*, const mdisp_image* dL, const mdisp_image* dR, flo
 int mdisp_build_rectify_maps(const double K[9], const double* dist, int ndist, const double R[9],
                              const double P[12], int width, int height, int16_t* map1, uint16_t* map2);
 
+/* cv::stereoRectify(K1, D1, K2, D2, size, R, T, R1, R2, P1, P2, Q, flags, alpha, size, &roi1, &roi2),
+ * methods/methods.cpp:1691-1694 (also :1143, :1512).  Host-side double arithmetic, row-major
+ * matrices, newImageSize = imageSize.  zero_disparity = 1 is CALIB_ZERO_DISPARITY; alpha < 0 keeps
+ * the averaged focal length, 0 <= alpha <= 1 scales it between "valid pixels only" and "all source
+ * pixels".  With alpha < 0 the results reproduce the known answer the reference stores in
+ * unditortStereoCalib.xml (Rectify_R1/R2/P1/P2/Q).  Q, roi1, roi2 may be NULL; roi = x, y, w, h. */
+int mdisp_stereo_rectify(const double K1[9], const double* D1, const double K2[9], const double* D2, int ndist,
+                         int width, int height, const double R[9], const double T[3], int zero_disparity,
+                         double alpha, double R1[9], double R2[9], double P1[12], double P2[12], double Q[16],
+                         int roi1[4], int roi2[4]);
+
 /* cv::remap(src, dst, map1, map2, INTER_LINEAR), methods/methods.cpp:1738,1745.
  * src/dst CV_8UC1 or CV_8UC3; maps as produced above, of dst's size. */
 int mdisp_remap(mdisp_ctx*, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst);

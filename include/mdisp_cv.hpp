@@ -7,6 +7,11 @@
 #define MDISP_CV_HPP
 
 #include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>   // resize(INTER_AREA) of getRectifiedImages stays on the host
+
+#include <algorithm>
+#include <string>
+#include <vector>
 
 #include "mdisp_host.hpp"
 
@@ -57,5 +62,55 @@ inline void steerFilter(cv::Mat src, cv::Mat& dst) { mdisp::steerFilter(src, dst
 
 // methods/methods.h:33
 inline void getDisparity_SGBM(cv::Mat srcLeft, cv::Mat srcRight, cv::Mat& disparityMap) { mdisp::getDisparity_SGBM(srcLeft, srcRight, disparityMap); }
+
+// methods/methods.h:27, methods/methods.cpp:1670-1766.  Same XML keys, same stereoRectify flags
+// (CALIB_ZERO_DISPARITY, alpha = 0), maps in CV_16SC2 fixed point, remap on the GPU; the 600-pixel
+// canvas, INTER_AREA resize and valid-ROI crop are kept as OpenCV host calls.  (The reference also
+// draws debugging rectangles and lines on its canvas after cloning the outputs; that is dropped.)
+inline void getRectifiedImages(cv::Mat imgLeft, cv::Mat imgRight, std::string cameraParaPath, cv::Mat& rectifiedLeft,
+                               cv::Mat& rectifiedRight)
+{
+    cv::Size imgSize;
+    cv::Mat K1, K2, D1, D2, R, T;
+    cv::FileStorage fn(cameraParaPath, cv::FileStorage::READ);
+    fn["ImgSize"] >> imgSize;
+    fn["Left_CameraInnerPara"] >> K1;   fn["Left_CameraDistPara"] >> D1;
+    fn["Right_CameraInnerPara"] >> K2;  fn["Right_CameraDistPara"] >> D2;
+    fn["R2L_Rotation_Matrix"] >> R;     fn["R2L_Translate_Matrix"] >> T;
+    fn.release();
+    auto dbl = [](const cv::Mat& m) { cv::Mat d; m.reshape(1, 1).convertTo(d, CV_64F); return d.clone(); };
+    K1 = dbl(K1); K2 = dbl(K2); D1 = dbl(D1); D2 = dbl(D2); R = dbl(R); T = dbl(T);
+    double R1[9], R2[9], P1[12], P2[12], Q[16];
+    int roi[2][4];
+    mdisp::detail::check(mdisp_stereo_rectify(K1.ptr<double>(), D1.ptr<double>(), K2.ptr<double>(), D2.ptr<double>(), (int)D1.total(),
+                                              imgSize.width, imgSize.height, R.ptr<double>(), T.ptr<double>(), 1, 0.0,
+                                              R1, R2, P1, P2, Q, roi[0], roi[1]));
+    const bool isVerticalStereo = std::fabs(P2[7]) > std::fabs(P2[3]);
+    if (imgLeft.rows != imgRight.rows && imgLeft.cols != imgRight.cols && imgLeft.rows != imgSize.height && imgLeft.cols != imgSize.width) {
+        std::cout << "img reading error" << std::endl;
+        return;
+    }
+    if (imgLeft.empty() || imgRight.empty()) return;
+    const double sf = (isVerticalStereo ? 300. : 600.) / std::max(imgSize.width, imgSize.height);
+    const int w = cvRound(imgSize.width * sf), h = cvRound(imgSize.height * sf);
+    cv::Mat out[2];
+    cv::Rect vroi[2];
+    for (int k = 0; k < 2; k++) {
+        const cv::Mat& src = k == 0 ? imgLeft : imgRight;
+        std::vector<int16_t> m1((size_t)imgSize.area() * 2);
+        std::vector<uint16_t> m2((size_t)imgSize.area());
+        mdisp::detail::check(mdisp_build_rectify_maps(k == 0 ? K1.ptr<double>() : K2.ptr<double>(), k == 0 ? D1.ptr<double>() : D2.ptr<double>(),
+                                                      (int)D1.total(), k == 0 ? R1 : R2, k == 0 ? P1 : P2, imgSize.width, imgSize.height,
+                                                      m1.data(), m2.data()));
+        cv::Mat rimg(imgSize, src.type());
+        mdisp_image s = mdisp::mat_traits<cv::Mat>::view(src), d = mdisp::mat_traits<cv::Mat>::view(rimg);
+        mdisp::detail::check(mdisp_remap(mdisp::Context::forThisThread().handle(), &s, m1.data(), m2.data(), &d));
+        cv::resize(rimg, out[k], cv::Size(w, h), 0, 0, cv::INTER_AREA);
+        vroi[k] = cv::Rect(cvRound(roi[k][0] * sf), cvRound(roi[k][1] * sf), cvRound(roi[k][2] * sf), cvRound(roi[k][3] * sf));
+    }
+    const cv::Rect v = vroi[0] & vroi[1];
+    rectifiedLeft = out[0](v).clone();
+    rectifiedRight = out[1](v).clone();
+}
 
 #endif  // MDISP_CV_HPP

@@ -116,8 +116,8 @@ void orc_init_undistort_rectify_map(const double K[9], const double* dist, int n
 void orc_remap_bilinear_u8(const uint8_t* src, int sH, int sW, int cn, const int16_t* map1, const uint16_t* map2,
                            int dH, int dW, uint8_t* dst);
 void orc_stereo_rectify(const double K1[9], const double* D1, const double K2[9], const double* D2, int ndist,
-                        int W, int H, const double R[9], const double T[3],
-                        double R1[9], double R2[9], double P1[12], double P2[12], double Q[16],
+                        int W, int H, const double R[9], const double T[3], double alpha, int zero_disparity,
+                        int global_rotation, double R1[9], double R2[9], double P1[12], double P2[12], double Q[16],
                         int roi1[4], int roi2[4]);
 
 #ifdef __cplusplus

@@ -253,3 +253,22 @@ def remap(src, map1, map2):
     dst = np.empty((dH, dW) + ((cn,) if src.ndim == 3 else ()), np.uint8)
     lib().orc_remap_bilinear_u8(_p(src), src.shape[0], src.shape[1], cn, _p(m1), _p(m2), dH, dW, _p(dst))
     return dst
+
+
+def stereo_rectify(K1, D1, K2, D2, size, R, T, alpha=-1.0, zero_disparity=True, global_rotation=0):
+    """cv::stereoRectify restatement -> dict(R1, R2, P1, P2, Q, roi1, roi2)."""
+    W, H = size
+    f = lambda a, n: np.ascontiguousarray(a, np.float64).reshape(n)  # noqa: E731
+    K1, K2, R, T = f(K1, 9), f(K2, 9), f(R, 9), f(T, 3)
+    D1 = np.ascontiguousarray(D1, np.float64).reshape(-1)
+    D2 = np.ascontiguousarray(D2, np.float64).reshape(-1)
+    assert D1.size == D2.size
+    R1, R2, P1, P2, Q = (np.empty(n, np.float64) for n in (9, 9, 12, 12, 16))
+    roi1, roi2 = np.empty(4, np.int32), np.empty(4, np.int32)
+    fn = lib().orc_stereo_rectify
+    fn.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 7
+    fn.restype = None
+    fn(_p(K1), _p(D1), _p(K2), _p(D2), D1.size, W, H, _p(R), _p(T), float(alpha), 1 if zero_disparity else 0, int(global_rotation),
+       _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), _p(roi1), _p(roi2))
+    return {"R1": R1.reshape(3, 3), "R2": R2.reshape(3, 3), "P1": P1.reshape(3, 4), "P2": P2.reshape(3, 4),
+            "Q": Q.reshape(4, 4), "roi1": tuple(int(v) for v in roi1), "roi2": tuple(int(v) for v in roi2)}
