@@ -39,7 +39,7 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -69,6 +69,17 @@ extern "C" int mdisp_synchronize(mdisp_ctx* c)
 {
     MD_REQUIRE(c, MDISP_E_BADARG, "null context");
     MD_HIP(hipStreamSynchronize(c->stream));
+    return md_check_sgm_error(c);
+}
+
+int md_check_sgm_error(mdisp_ctx* c)
+{
+    if (!c->sgm_err) return MDISP_OK;
+    int flag = 0;
+    const int* p = c->sgm_err;
+    c->sgm_err = nullptr;
+    MD_HIP(hipMemcpy(&flag, p, sizeof(int), hipMemcpyDeviceToHost));
+    MD_REQUIRE(flag == 0, MDISP_E_HIP, "SGM sweep pipeline: a strip waited too long for its neighbour (results are invalid)");
     return MDISP_OK;
 }
 
@@ -469,7 +480,7 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     if ((rc = md_sgm_run(c, pl, base + o_l, base + o_r, pitch, 0, (int16_t*)(base + o_d), base + o_ws))) return rc;
     MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, c->stream));
     MD_HIP(hipStreamSynchronize(c->stream));
-    return MDISP_OK;
+    return md_check_sgm_error(c);
 }
 
 extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* Sh)
@@ -493,7 +504,7 @@ extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp
     if ((rc = md_sgm_aggregate_only(c, pl, base + o_l, base + o_r, pitch, base + o_ws, &S))) return rc;
     MD_HIP(hipMemcpy2DAsync(Sh, (size_t)pl.D * 2, S, (size_t)pl.sstride * 2, (size_t)pl.D * 2, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
     MD_HIP(hipStreamSynchronize(c->stream));
-    return MDISP_OK;
+    return md_check_sgm_error(c);
 }
 
 // ---------------------------------------------------------------------------------------------

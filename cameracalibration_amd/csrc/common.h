@@ -39,7 +39,10 @@ struct mdisp_ctx {
     bool timing;
     hipEvent_t ev[6];    // [0,1] whole call, [2,3] SGM aggregation, [4,5] separate WTA kernel
     bool ev_valid[3];
+    const int* sgm_err;  // device error word of the last pipelined SGM call (0 = fine), or null
 };
+// after the stream has been synchronised: fails if the last SGM call reported a hand-off timeout
+int md_check_sgm_error(mdisp_ctx* ctx);
 
 // grow-only workspace; returns nullptr on failure (error set)
 void* mdisp_ws(mdisp_ctx* ctx, size_t bytes);
@@ -71,7 +74,7 @@ bool md_sgm2_supported(const md_sgm_plan& pl);
 size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode);
 bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp);
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord);
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
                int16_t* dDisp, void* ws);

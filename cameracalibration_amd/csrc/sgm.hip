@@ -332,7 +332,7 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
     if (pl.use_v2) {
         rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch,
-                               dDisp ? 0 : 1, dDisp);
+                               dDisp ? 0 : 1, dDisp, &ctx->sgm_err);
         if (rc) return rc;
     } else {
         for (int i = 0; i < pl.batch; i++) {

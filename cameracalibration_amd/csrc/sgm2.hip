@@ -181,6 +181,79 @@ __device__ __forceinline__ void unpack_bytes(const uint4& w, u32 (&L)[NR])
     }
 }
 
+// Winner-take-all on the 16 aggregated costs each lane of a lane-row holds (register order): first
+// minimum over d, the smallest cost outside {best-1, best, best+1} for the uniqueness test, and the
+// two neighbours of the minimum for the parabola fit (through `srow`, this lane-row's 128 dwords
+// of LDS).  Lane 0 of the lane-row writes the record.
+template <bool TAIL>
+__device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[NR], const u32 (&tail)[NR], int lic, u32* srow,
+                                          const u32 (*exclMask)[NR], size_t recIndex)
+{
+    // packed keys (S << 4 | local index), then (S, d) across the 16 lanes
+    u32 kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const u32 idx = (u32)(4 * (q >> 1) + (q & 1)) | ((u32)(4 * (q >> 1) + (q & 1) + 2) << 16);
+        u32 k = asu(asv(Sacc[q]) * (unsigned short)16 + asv(idx));
+        if (TAIL) k |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+        kmin = q == 0 ? k : pkmin(kmin, k);
+    }
+    const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
+    u32 key = ((kl >> 4) << 16) | (u32)(lic * DPL) | (kl & 15u);
+    key = row_min16(key);
+    const int best = (int)(key & 0xFFFFu);
+    const int minS = (int)(key >> 16);
+    // smallest S outside {best-1, best, best+1}
+    const int rel = best - lic * DPL;
+    const int tsel = (unsigned)(rel + 1) <= 17u ? rel + 1 : 18;
+    const uint4 m0 = *reinterpret_cast<const uint4*>(&exclMask[tsel][0]);
+    const uint4 m1 = *reinterpret_cast<const uint4*>(&exclMask[tsel][4]);
+    const u32 em[NR] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    u32 smin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        u32 v = Sacc[q] | em[q];
+        if (TAIL) v |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+        smin = q == 0 ? v : pkmin(smin, v);
+    }
+    const int mex = (int)row_min16(min(smin & 0xFFFFu, smin >> 16));
+    // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
+    const bool notUnique = mex != 0xFFFF && (mex - a.bias) * (100 - a.uniq) < (minS - a.bias) * 100;
+    {
+        uint4* dst = reinterpret_cast<uint4*>(&srow[lic * 8]);
+        dst[0] = make_uint4(Sacc[0], Sacc[1], Sacc[2], Sacc[3]);
+        dst[1] = make_uint4(Sacc[4], Sacc[5], Sacc[6], Sacc[7]);
+    }
+    auto s_at = [&](int d) -> u32 {
+        d = min(max(d, 0), 255);
+        const int e = d & 15;
+        const int reg = 2 * (e >> 2) + (e & 1), half = (e >> 1) & 1;
+        return (srow[(d >> 4) * 8 + reg] >> (16 * half)) & 0xFFFFu;
+    };
+    const u32 sm = s_at(best - 1), spl = s_at(best + 1);
+    if (lic == 0) {
+        uint2 rec;
+        rec.x = (u32)minS | ((u32)best << 16) | (notUnique ? 0x80000000u : 0u);
+        rec.y = sm | (spl << 16);
+        a.rec[recIndex] = rec;
+    }
+}
+
+// the 19 x NR table of masks fused_wta() uses: row t covers best - (lane base) = t - 1
+__device__ __forceinline__ void init_excl_mask(u32 (*exclMask)[NR])
+{
+    for (int i = threadIdx.x; i < 19 * NR; i += 256) {
+        const int t = i / NR, r = i % NR, rel = t - 1;
+        const int elo = 4 * (r >> 1) + (r & 1), ehi = elo + 2;
+        u32 m = 0;
+        if (t < 18) {
+            if (elo - rel >= -1 && elo - rel <= 1) m |= 0x0000FFFFu;
+            if (ehi - rel >= -1 && ehi - rel <= 1) m |= 0xFFFF0000u;
+        }
+        exclMask[t][r] = m;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Horizontal paths: one lane-row per (row, direction), 16 per workgroup; line id < H: (1,0), else (-1,0).
 template <bool TAIL, bool U8>
@@ -284,16 +357,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     __shared__ u32 srow[FUSE ? CW : 1][FUSE ? 128 : 1];      // S8 of the current row, register order
     __shared__ u32 exclMask[FUSE ? 19 : 1][NR];              // 0xFFFF over {best-1, best, best+1} by (best - lane base + 1)
     if (FUSE) {
-        for (int i = threadIdx.x; i < 19 * NR; i += 256) {
-            const int t = i / NR, r = i % NR, rel = t - 1;
-            const int elo = 4 * (r >> 1) + (r & 1), ehi = elo + 2;
-            u32 m = 0;
-            if (t < 18) {
-                if (elo - rel >= -1 && elo - rel <= 1) m |= 0x0000FFFFu;
-                if (ehi - rel >= -1 && ehi - rel <= 1) m |= 0xFFFF0000u;
-            }
-            exclMask[t][r] = m;
-        }
+        init_excl_mask(exclMask);
         __syncthreads();
     }
     const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
@@ -420,56 +484,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
                 dst[1] = make_uint4(NB[4], NB[5], NB[6], NB[7]);
             }
             if (FUSE) {
-                // ---- winner-take-all on S8 while it is still in registers ----
-                // first minimum over d: packed keys (S << 4 | local index), then (S, d) across the 16 lanes
-                u32 kmin = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    const u32 idx = (u32)(4 * (q >> 1) + (q & 1)) | ((u32)(4 * (q >> 1) + (q & 1) + 2) << 16);
-                    u32 k = asu(asv(Sacc[q]) * (unsigned short)16 + asv(idx));
-                    if (TAIL) k |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
-                    kmin = q == 0 ? k : pkmin(kmin, k);
-                }
-                const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
-                u32 key = ((kl >> 4) << 16) | (u32)(lic * DPL) | (kl & 15u);
-                key = row_min16(key);
-                const int best = (int)(key & 0xFFFFu);
-                const int minS = (int)(key >> 16);
-                // smallest S outside {best-1, best, best+1}
-                const int rel = best - lic * DPL;
-                const int tsel = (unsigned)(rel + 1) <= 17u ? rel + 1 : 18;
-                const uint4 m0 = *reinterpret_cast<const uint4*>(&exclMask[tsel][0]);
-                const uint4 m1 = *reinterpret_cast<const uint4*>(&exclMask[tsel][4]);
-                const u32 em[NR] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-                u32 smin = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    u32 v = Sacc[q] | em[q];
-                    if (TAIL) v |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
-                    smin = q == 0 ? v : pkmin(smin, v);
-                }
-                const int mex = (int)row_min16(min(smin & 0xFFFFu, smin >> 16));
-                // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
-                const bool notUnique = mex != 0xFFFF && (mex - a.bias) * (100 - a.uniq) < (minS - a.bias) * 100;
-                // neighbours of the minimum for the parabola fit, through LDS (register order)
-                {
-                    uint4* dst = reinterpret_cast<uint4*>(&srow[lr][lic * 8]);
-                    dst[0] = make_uint4(Sacc[0], Sacc[1], Sacc[2], Sacc[3]);
-                    dst[1] = make_uint4(Sacc[4], Sacc[5], Sacc[6], Sacc[7]);
-                }
-                auto s_at = [&](int d) -> u32 {
-                    d = min(max(d, 0), 255);
-                    const int e = d & 15;
-                    const int reg = 2 * (e >> 2) + (e & 1), half = (e >> 1) & 1;
-                    return (srow[lr][(d >> 4) * 8 + reg] >> (16 * half)) & 0xFFFFu;
-                };
-                const u32 sm = s_at(best - 1), spl = s_at(best + 1);
-                if (lic == 0) {
-                    uint2 rec;
-                    rec.x = (u32)minS | ((u32)best << 16) | (notUnique ? 0x80000000u : 0u);
-                    rec.y = sm | (spl << 16);
-                    a.rec[(size_t)pair * a.strideRec + (size_t)y * W + x] = rec;
-                }
+                fused_wta<TAIL>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + (size_t)y * W + x);
             } else if (UP && a.naturalOut) {
                 // [A_g.lo|B_g.lo], [A_g.hi|B_g.hi]: pairs of consecutive disparities
                 u32 nat[NR];
@@ -482,6 +497,228 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
             } else store8(sp, Sacc);
         }
         __syncthreads();   // diag[par] complete before the next row reads it
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sheared sweep (byte-state mode only): the same three paths per sweep as sgm2_sweep_kernel, but a
+// workgroup owns 16 columns of the SHEARED frame c = x - y.  In that frame
+//   down sweep:  (1,1)  stays in its column (registers),  (0,1) arrives from c+1,  (-1,1) from c+2
+//   up sweep:    (-1,-1) stays in its column,             (0,-1) arrives from c-1, (1,-1) from c-2
+// so every cross-strip dependency points the same way and neighbouring strips form a pipeline:
+// a strip hands the states of its two outermost columns to the next strip through global memory,
+// one row at a time, and no separate pass over the diagonals is needed.
+//
+// Protocol (one direction only, so it cannot deadlock): workgroups take a ticket when they start;
+// ticket order is strip order along the dependency direction (all pairs of strip k before any
+// pair of the strip that depends on it), so a workgroup only ever waits for one that started
+// earlier.  A fifth "communication" wave does the exchange: it writes the edge states with
+// agent-scope (write-through) stores, drains them (vmcnt(0)) and then publishes "rows done" in the
+// strip's progress word; on the consuming side it reads the neighbour's progress word and states
+// with agent-scope loads and parks them in LDS for the compute waves.  Every wait is bounded: on
+// timeout the error word is set, all waits stop and the host reports the failure.
+struct ShearArgs {
+    Sgm2Args a;
+    u8* hand;               // [B][H][nsh][3][256]: per row and strip, V of m=0, B of m=0, B of m=1
+    size_t strideHand;      // bytes per pair
+    int* sync;              // [0] ticket (down) [1] ticket (up) [2] error, [16 + (sweep*B + pair)*nsh + k] progress
+    int nsh, cmin, batch;
+};
+constexpr int SHEAR_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ void hand_store(u8* p, const uint4& v)
+{
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint4 hand_load(const u8* p)
+{
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+}
+
+template <bool UP, bool TAIL, bool FUSE>
+__global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
+{
+    const Sgm2Args& a = sa.a;
+    __shared__ u32 vs[2][CW][64];      // vertical-path states of the previous / current row, as bytes
+    __shared__ u32 bs[2][CW][64];      // states of the diagonal that crosses two sheared columns per row
+    __shared__ u32 hin[2][3][64];      // neighbour strip's states for the current / next row: V->m15, B->m14, B->m15
+    __shared__ u32 srow[FUSE ? CW : 1][FUSE ? 128 : 1];
+    __shared__ u32 exclMask[FUSE ? 19 : 1][NR];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sa.sync[UP ? 1 : 0], 1);
+    if (FUSE) init_excl_mask(exclMask);
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int ord = ticket / sa.batch, pair = ticket - ord * sa.batch;
+    const int k = UP ? ord : sa.nsh - 1 - ord;              // strips in dependency order
+    const int H = a.H, W = a.W;
+    const int c0 = sa.cmin + CW * k;
+    const int ylo = max(0, -(c0 + CW - 1)), yhi = min(H, W - c0);   // rows in which the strip touches the image
+    const int nrows = yhi - ylo;
+    if (nrows <= 0) return;
+    const int sy = UP ? -1 : 1, ys = UP ? yhi - 1 : ylo;
+    u8* hand = sa.hand + (size_t)pair * sa.strideHand;
+    const int nbk = UP ? k - 1 : k + 1;
+    const bool hasNb = nbk >= 0 && nbk < sa.nsh;
+    auto has_prev = [&](int y) { return UP ? y < H - 1 : y > 0; };
+    auto hand_slot = [&](int y, int strip, int which, int lic) -> u8* {
+        return hand + ((((size_t)y * sa.nsh + strip) * 3 + which) * 256 + lic * 16);
+    };
+
+    if (threadIdx.x >= 256) {
+        // ---- communication wave: publishes this strip's edge states one row behind the compute
+        // waves and fetches the neighbour's one row ahead of them, so that neither the write-through
+        // drain nor a wait for a slow neighbour sits in the compute waves' instruction stream
+        const int lane = threadIdx.x - 256, which = lane >> 4, lic = lane & 15;
+        int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
+        const int* progNb = progMe + (UP ? -1 : 1);
+        int* errWord = sa.sync + 2;
+        int seen = 0;
+        // m = 15 sits in sheared column c0 + 15 (down) / c0 (up); m = 14 next to it
+        const int c15 = UP ? c0 : c0 + CW - 1, c14 = UP ? c0 + 1 : c0 + CW - 2;
+        auto fetch = [&](int i) {
+            const int y = ys + sy * i;
+            if (!hasNb || !has_prev(y)) return;
+            const int x15 = c15 + y, x14 = c14 + y;
+            const bool in15 = x15 >= 0 && x15 < W, in14 = x14 >= 0 && x14 < W;
+            const bool wantV = in15;
+            const bool wantB14 = in14 && (UP ? x14 != 0 : x14 != W - 1);
+            const bool wantB15 = in15 && (UP ? x15 != 0 : x15 != W - 1);
+            if (!(wantV || wantB14 || wantB15)) return;
+            const int need = UP ? H - 1 - y : y;         // rows the neighbour must have published
+            if (seen < need) {
+                for (int it = 0;; it++) {
+                    seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= need) break;
+                    if (it > SHEAR_SPIN_LIMIT || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        seen = 0x7FFFFFFF;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            }
+            const bool mine = which == 0 ? wantV : (which == 1 ? wantB14 : (which == 2 ? wantB15 : false));
+            if (mine) {
+                const uint4 w = hand_load(hand_slot(y - sy, nbk, which, lic));
+                *reinterpret_cast<uint4*>(&hin[i & 1][which][lic * 4]) = w;
+            }
+        };
+        auto publish = [&](int i) {    // row i has been computed and its states are in vs/bs[i & 1]
+            const int y = ys + sy * i, par = i & 1;
+            if (which < 3) {
+                const uint4 w = which == 0 ? *reinterpret_cast<const uint4*>(&vs[par][0][lic * 4])
+                                           : *reinterpret_cast<const uint4*>(&bs[par][which - 1][lic * 4]);
+                hand_store(hand_slot(y, k, which, lic), w);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(progMe, (UP ? H - 1 - y : y) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        fetch(0);
+        __syncthreads();
+        for (int i = 0; i < nrows; i++) {
+            if (i > 0) publish(i - 1);
+            if (i + 1 < nrows) fetch(i + 1);
+            __syncthreads();
+        }
+        publish(nrows - 1);
+        return;
+    }
+
+    // ---- compute waves ----
+    const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
+    const int m = UP ? 15 - lr : lr;                          // column index counted against the dependency direction
+    const int c = c0 + lr;
+    const u8* cLp = a.cL + (size_t)pair * a.strideL;
+    const u8* cRp = a.cR + (size_t)pair * a.strideR;
+    u16* Sp = a.S + (size_t)pair * a.strideS;
+    const u8* Hp = a.Hvol[UP ? 1 : 0] + (size_t)pair * a.strideH;
+    u32 tail[NR];
+    make_tail(lic, a.D, tail);
+    const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
+    auto fresh = [&](u32 (&N)[NR]) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) N[q] = TAIL ? tail[q] : 0u;
+    };
+    auto from_bytes = [&](const uint4& w, u32 (&N)[NR]) {
+        unpack_bytes(w, N);
+        if (TAIL) {
+#pragma unroll
+            for (int q = 0; q < NR; q++) N[q] |= tail[q];
+        }
+    };
+    u32 Nr[NR];                        // the diagonal that stays in this sheared column
+    fresh(Nr);
+    u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0);
+    u32 Snext[NR];
+    auto fetch_row = [&](int i) {
+        const int y = ys + sy * i, x = c + y;
+        if (x >= 0 && x < W) {
+            load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
+            const size_t pix = (size_t)y * W + x;
+            hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
+            if (UP) load8(Sp + (pix * 256 + lic * DPL), Snext);
+        }
+    };
+    fetch_row(0);
+    __syncthreads();                   // the communication wave has fetched the first row's neighbour states
+    for (int i = 0; i < nrows; i++) {
+        const int y = ys + sy * i, x = c + y;
+        const bool active = x >= 0 && x < W;
+        const bool hasPrev = has_prev(y);
+        const int par = i & 1;
+        u32 C[NR], L[NR], Sacc[NR];
+        if (active) {
+            cost_from_operands(cl, rb, C);
+            unpack_bytes(hb, Sacc);
+            if (UP) {
+#pragma unroll
+                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+            }
+        }
+        if (i + 1 < nrows) fetch_row(i + 1);
+        if (active) {
+            // diagonal resident in this column: predecessor (x-1, y-1) going down, (x+1, y+1) going up
+            if (!hasPrev || (UP ? x == W - 1 : x == 0)) fresh(Nr);
+            sgm_step<TAIL>(Nr, C, P1P1, P2P2, tail, L);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            // vertical path: predecessor (x, y -+ 1) lives one sheared column further
+            u32 N[NR];
+            if (!hasPrev) fresh(N);
+            else if (m < 15) from_bytes(*reinterpret_cast<const uint4*>(&vs[par ^ 1][m + 1][lic * 4]), N);
+            else from_bytes(*reinterpret_cast<const uint4*>(&hin[par][0][lic * 4]), N);
+            sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            *reinterpret_cast<uint4*>(&vs[par][m][lic * 4]) = pack_bytes(N);
+            // the other diagonal: predecessor (x+1, y-1) going down, (x-1, y+1) going up, two columns further
+            if (!hasPrev || (UP ? x == 0 : x == W - 1)) fresh(N);
+            else if (m < 14) from_bytes(*reinterpret_cast<const uint4*>(&bs[par ^ 1][m + 2][lic * 4]), N);
+            else from_bytes(*reinterpret_cast<const uint4*>(&hin[par][m - 13][lic * 4]), N);
+            sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            *reinterpret_cast<uint4*>(&bs[par][m][lic * 4]) = pack_bytes(N);
+            const size_t pix = (size_t)y * W + x;
+            if (FUSE) fused_wta<TAIL>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
+            else if (UP && a.naturalOut) {
+                u32 nat[NR];
+#pragma unroll
+                for (int g = 0; g < NR / 2; g++) {
+                    nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+                    nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                }
+                store8(Sp + (pix * 256 + lic * DPL), nat);
+            } else store8(Sp + (pix * 256 + lic * DPL), Sacc);
+        }
+        __syncthreads();   // vs/bs[par] complete before the next row reads them
     }
 }
 
@@ -546,13 +783,20 @@ __global__ __launch_bounds__(256) void sgm2_lr_kernel(LrArgs a)
 
 static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin + pl.P2 <= 255; }
 
+static int shear_strips(int H, int W) { return (W + H - 1 + CW - 1) / CW; }
+static size_t shear_hand_bytes(int H, int W) { return md_align((size_t)H * shear_strips(H, W) * 3 * 256, 256); }
+static size_t shear_sync_bytes(int H, int W, int batch) { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W)) * sizeof(int), 256); }
+// the pipelined sheared sweeps replace the border pre-pass whenever path values fit a byte
+static bool use_shear(bool u8mode) { return u8mode && !getenv("MDISP_SGM_PREPASS"); }
+
 size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode)
 {
     const int nstrips = (W + CW - 1) / CW;
-    const size_t bnd = md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 4;
+    size_t bnd = md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 4;
+    if (u8mode && shear_hand_bytes(H, W) > bnd) bnd = shear_hand_bytes(H, W);
     const size_t hvol = md_align((size_t)H * W * 256 * (u8mode ? 1 : 2), 256) * 2;
     const size_t rec = md_align((size_t)H * W * sizeof(uint2), 256);
-    return (bnd + hvol + rec) * batch;
+    return (bnd + hvol + rec) * batch + shear_sync_bytes(H, W, batch);
 }
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
@@ -567,9 +811,10 @@ bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
 // naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
 // naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp)
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord)
 {
     Sgm2Args a;
+    if (errWord) *errWord = nullptr;
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
     a.cR = cR; a.pR = pl.pitchR; a.strideR = strideR;
     a.S = S; a.strideS = strideS;
@@ -577,10 +822,12 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.nstrips = (pl.W + CW - 1) / CW;
     const bool u8m = fits_u8(pl);
     const size_t oneB = md_align((size_t)pl.H * a.nstrips * 256 * sizeof(u16), 256);
+    size_t bndBytes = 4 * oneB;                       // per pair: four border-state planes, or the hand-off rows
+    if (u8m && shear_hand_bytes(pl.H, pl.W) > bndBytes) bndBytes = shear_hand_bytes(pl.H, pl.W);
     for (int i = 0; i < 4; i++) a.bnd[i] = (u16*)(extra + (size_t)i * oneB * batch);
     a.strideB = oneB / sizeof(u16);
     const size_t oneH = md_align((size_t)pl.H * pl.W * 256 * (u8m ? 1 : 2), 256);
-    u8* hbase = extra + 4 * oneB * batch;
+    u8* hbase = extra + bndBytes * batch;
     a.Hvol[0] = hbase; a.Hvol[1] = hbase + oneH * batch;
     a.strideH = oneH;
     a.P1P1 = (u32)pl.P1 | ((u32)pl.P1 << 16);
@@ -591,6 +838,26 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.rec = (uint2*)(hbase + 2 * oneH * batch);
     a.strideRec = oneRec / sizeof(uint2);
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
+    if (use_shear(u8m)) {
+        ShearArgs sa;
+        sa.a = a;
+        sa.hand = extra; sa.strideHand = bndBytes;
+        sa.sync = (int*)(hbase + 2 * oneH * batch + oneRec * batch);
+        sa.nsh = shear_strips(pl.H, pl.W); sa.cmin = -(pl.H - 1); sa.batch = batch;
+        MD_HIP(hipMemsetAsync(sa.sync, 0, shear_sync_bytes(pl.H, pl.W, batch), s));
+        if (errWord) *errWord = sa.sync + 2;
+        dim3 gh((2 * pl.H + 15) / 16, batch), gs((unsigned)sa.nsh * batch);
+#define SGM2_SHEAR(TAILV)                                                                 \
+        do {                                                                              \
+            sgm2_hscan_kernel<TAILV, true><<<gh, 256, 0, s>>>(a);                         \
+            sgm2_shear_kernel<false, TAILV, false><<<gs, 320, 0, s>>>(sa);                \
+            if (naturalOut) sgm2_shear_kernel<true, TAILV, false><<<gs, 320, 0, s>>>(sa); \
+            else sgm2_shear_kernel<true, TAILV, true><<<gs, 320, 0, s>>>(sa);             \
+        } while (0)
+        if (a.tail) SGM2_SHEAR(true); else SGM2_SHEAR(false);
+#undef SGM2_SHEAR
+        MD_HIP(hipGetLastError());
+    } else {
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
     do {                                                                 \
@@ -604,6 +871,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     else { if (u8m) SGM2_LAUNCH(false, true); else SGM2_LAUNCH(false, false); }
 #undef SGM2_LAUNCH
     MD_HIP(hipGetLastError());
+    }
     if (!naturalOut) {
         LrArgs l;
         l.rec = a.rec; l.strideRec = a.strideRec; l.H = pl.H; l.W = pl.W; l.D = pl.D; l.minD = pl.minD;
