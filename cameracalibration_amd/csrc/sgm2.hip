@@ -155,6 +155,30 @@ __device__ __forceinline__ void store8(u16* p, const u32 (&v)[NR])
     reinterpret_cast<uint4*>(p)[0] = make_uint4(v[0], v[1], v[2], v[3]);
     reinterpret_cast<uint4*>(p)[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
+// streaming variants: the volumes are written once and read once, far apart in time
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store8_stream(u16* p, const u32 (&v)[NR])
+{
+    u32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(p) + 1);
+}
+__device__ __forceinline__ void load8_stream(const u16* p, u32 (&v)[NR])
+{
+    const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + 1);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store16_stream(u8* p, const uint4& w)
+{
+    u32x4 a = {w.x, w.y, w.z, w.w};
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p));
+}
+__device__ __forceinline__ uint4 load16_stream(const u8* p)
+{
+    const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(a.x, a.y, a.z, a.w);
+}
 __device__ __forceinline__ void zero8(u32 (&v)[NR])
 {
 #pragma unroll
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
         cost_from_operands(cl, rb, C);
         if (t + 1 < W) load_cost_operands(a, cLrow, cRrow, x + dx, lic, cl, rb);
         sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
-        if (U8) *reinterpret_cast<uint4*>(hrow + (size_t)x * 256) = pack_bytes(L);
+        if (U8) store16_stream(hrow + (size_t)x * 256, pack_bytes(L));
         else store8(reinterpret_cast<u16*>(hrow + (size_t)x * 512), L);
         x += dx;
     }
@@ -523,6 +547,8 @@ struct ShearArgs {
     size_t strideHand;      // bytes per pair
     int* sync;              // [0] ticket (down) [1] ticket (up) [2] error, [16 + (sweep*B + pair)*nsh + k] progress
     int nsh, cmin, batch;
+    int debugNoWait;        // measurement only (results are wrong): bit0 skip neighbour waits, bit1 skip S stores,
+                            // bit2 skip H/S loads, bit3 skip the per-row barrier
 };
 constexpr int SHEAR_SPIN_LIMIT = 1 << 22;
 
@@ -540,7 +566,7 @@ __device__ __forceinline__ uint4 hand_load(const u8* p)
     return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
-template <bool UP, bool TAIL, bool FUSE>
+template <bool UP, bool TAIL, bool FUSE, bool S4B>
 __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
 {
     const Sgm2Args& a = sa.a;
@@ -578,21 +604,26 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
         const int* progNb = progMe + (UP ? -1 : 1);
         int* errWord = sa.sync + 2;
-        int seen = 0;
+        int seen = (sa.debugNoWait & 1) ? 0x7FFFFFFF : 0;
         // m = 15 sits in sheared column c0 + 15 (down) / c0 (up); m = 14 next to it
         const int c15 = UP ? c0 : c0 + CW - 1, c14 = UP ? c0 + 1 : c0 + CW - 2;
-        auto fetch = [&](int i) {
+        // does this lane fetch a neighbour state for row i?
+        auto wants = [&](int i) -> bool {
             const int y = ys + sy * i;
-            if (!hasNb || !has_prev(y)) return;
-            const int x15 = c15 + y, x14 = c14 + y;
-            const bool in15 = x15 >= 0 && x15 < W, in14 = x14 >= 0 && x14 < W;
-            const bool wantV = in15;
-            const bool wantB14 = in14 && (UP ? x14 != 0 : x14 != W - 1);
-            const bool wantB15 = in15 && (UP ? x15 != 0 : x15 != W - 1);
-            if (!(wantV || wantB14 || wantB15)) return;
+            if (!hasNb || !has_prev(y) || which > 2) return false;
+            const int x = (which == 1 ? c14 : c15) + y;
+            if (x < 0 || x >= W) return false;
+            return which == 0 || (UP ? x != 0 : x != W - 1);
+        };
+        // request the neighbour states row i consumes; waits (bounded) until the neighbour has published them
+        auto request = [&](int i, uint4& w) {
+            const bool mine = wants(i);
+            if (!__any(mine)) return;
+            const int y = ys + sy * i;
             const int need = UP ? H - 1 - y : y;         // rows the neighbour must have published
             if (seen < need) {
-                for (int it = 0;; it++) {
+                int it = 0;
+                for (;; it++) {
                     seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (seen >= need) break;
                     if (it > SHEAR_SPIN_LIMIT || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -603,31 +634,45 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                     __builtin_amdgcn_s_sleep(2);
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if ((sa.debugNoWait & 16) && lane == 0) { atomicAdd(&sa.sync[4 + (UP ? 4 : 0)], 1); atomicAdd(&sa.sync[5 + (UP ? 4 : 0)], it); if (it == 0) atomicAdd(&sa.sync[6 + (UP ? 4 : 0)], 1); atomicAdd(&sa.sync[7 + (UP ? 4 : 0)], seen - need); }
             }
-            const bool mine = which == 0 ? wantV : (which == 1 ? wantB14 : (which == 2 ? wantB15 : false));
-            if (mine) {
-                const uint4 w = hand_load(hand_slot(y - sy, nbk, which, lic));
-                *reinterpret_cast<uint4*>(&hin[i & 1][which][lic * 4]) = w;
-            }
+            if (mine) w = hand_load(hand_slot(y - sy, nbk, which, lic));
         };
-        auto publish = [&](int i) {    // row i has been computed and its states are in vs/bs[i & 1]
-            const int y = ys + sy * i, par = i & 1;
+        auto park = [&](int i, const uint4& w) {          // hand the fetched states of row i to the compute waves
+            if (wants(i)) *reinterpret_cast<uint4*>(&hin[i & 1][which][lic * 4]) = w;
+        };
+        auto send = [&](int i) {                           // row i has been computed: its edge states are in vs/bs[i & 1]
             if (which < 3) {
+                const int par = i & 1;
                 const uint4 w = which == 0 ? *reinterpret_cast<const uint4*>(&vs[par][0][lic * 4])
                                            : *reinterpret_cast<const uint4*>(&bs[par][which - 1][lic * 4]);
-                hand_store(hand_slot(y, k, which, lic), w);
+                hand_store(hand_slot(ys + sy * i, k, which, lic), w);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        auto announce = [&](int i) {                       // rows up to i are in memory
+            const int y = ys + sy * i;
             if (lane == 0) __hip_atomic_store(progMe, (UP ? H - 1 - y : y) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        fetch(0);
+        // Software pipeline, one step per row and never waiting on an operation issued in the same
+        // step: step i drains what step i-1 issued (stores of row i-2, loads for row i+1), announces
+        // row i-2, parks row i+1's states in LDS, requests row i+2's and sends row i-1's.
+        uint4 w = make_uint4(0, 0, 0, 0);
+        request(0, w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park(0, w);
+        if (nrows > 1) request(1, w);
         __syncthreads();
         for (int i = 0; i < nrows; i++) {
-            if (i > 0) publish(i - 1);
-            if (i + 1 < nrows) fetch(i + 1);
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i >= 2) announce(i - 2);
+            if (i + 1 < nrows) park(i + 1, w);
+            if (i + 2 < nrows) request(i + 2, w);
+            if (i >= 1) send(i - 1);
+            if (!(sa.debugNoWait & 8)) __syncthreads();
         }
-        publish(nrows - 1);
+        send(nrows - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        announce(nrows - 1);
         return;
     }
 
@@ -657,13 +702,18 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     fresh(Nr);
     u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0);
     u32 Snext[NR];
+    uint4 sb = make_uint4(0, 0, 0, 0);
+    // S4B: the four-path partial sum fits a byte per disparity and travels as 256 bytes per pixel
+    u8* Sb = reinterpret_cast<u8*>(Sp);
     auto fetch_row = [&](int i) {
         const int y = ys + sy * i, x = c + y;
         if (x >= 0 && x < W) {
             load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
             const size_t pix = (size_t)y * W + x;
-            hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
-            if (UP) load8(Sp + (pix * 256 + lic * DPL), Snext);
+            if (!(sa.debugNoWait & 4)) {
+            hb = load16_stream(Hp + pix * 256 + lic * 16);
+            if (UP) { if (S4B) sb = load16_stream(Sb + pix * 256 + lic * 16); else load8_stream(Sp + (pix * 256 + lic * DPL), Snext); }
+            }
         }
     };
     fetch_row(0);
@@ -678,6 +728,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
             cost_from_operands(cl, rb, C);
             unpack_bytes(hb, Sacc);
             if (UP) {
+                if (S4B) unpack_bytes(sb, Snext);
 #pragma unroll
                 for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
             }
@@ -716,9 +767,10 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                     nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
                 store8(Sp + (pix * 256 + lic * DPL), nat);
-            } else store8(Sp + (pix * 256 + lic * DPL), Sacc);
+            } else if (S4B) store16_stream(Sb + pix * 256 + lic * 16, pack_bytes(Sacc));
+            else if (!(sa.debugNoWait & 2)) store8_stream(Sp + (pix * 256 + lic * DPL), Sacc);
         }
-        __syncthreads();   // vs/bs[par] complete before the next row reads them
+        if (!(sa.debugNoWait & 8)) __syncthreads();   // vs/bs[par] complete before the next row reads them
     }
 }
 
@@ -844,19 +896,30 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         sa.hand = extra; sa.strideHand = bndBytes;
         sa.sync = (int*)(hbase + 2 * oneH * batch + oneRec * batch);
         sa.nsh = shear_strips(pl.H, pl.W); sa.cmin = -(pl.H - 1); sa.batch = batch;
+        sa.debugNoWait = getenv("MDISP_SHEAR_DEBUG") ? atoi(getenv("MDISP_SHEAR_DEBUG")) : 0;
         MD_HIP(hipMemsetAsync(sa.sync, 0, shear_sync_bytes(pl.H, pl.W, batch), s));
         if (errWord) *errWord = sa.sync + 2;
         dim3 gh((2 * pl.H + 15) / 16, batch), gs((unsigned)sa.nsh * batch);
-#define SGM2_SHEAR(TAILV)                                                                 \
-        do {                                                                              \
-            sgm2_hscan_kernel<TAILV, true><<<gh, 256, 0, s>>>(a);                         \
-            sgm2_shear_kernel<false, TAILV, false><<<gs, 320, 0, s>>>(sa);                \
-            if (naturalOut) sgm2_shear_kernel<true, TAILV, false><<<gs, 320, 0, s>>>(sa); \
-            else sgm2_shear_kernel<true, TAILV, true><<<gs, 320, 0, s>>>(sa);             \
+#define SGM2_SHEAR(TAILV, S4BV)                                                                      \
+        do {                                                                                         \
+            sgm2_hscan_kernel<TAILV, true><<<gh, 256, 0, s>>>(a);                                    \
+            sgm2_shear_kernel<false, TAILV, false, S4BV><<<gs, 320, 0, s>>>(sa);                     \
+            if (naturalOut) sgm2_shear_kernel<true, TAILV, false, S4BV><<<gs, 320, 0, s>>>(sa);      \
+            else sgm2_shear_kernel<true, TAILV, true, S4BV><<<gs, 320, 0, s>>>(sa);                  \
         } while (0)
-        if (a.tail) SGM2_SHEAR(true); else SGM2_SHEAR(false);
+        // the down sweep's four-path sum stays below 256 for small P2: half the volume traffic
+        const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+        if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
+        else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
 #undef SGM2_SHEAR
         MD_HIP(hipGetLastError());
+        if (sa.debugNoWait & 16) {
+            int h[16];
+            MD_HIP(hipStreamSynchronize(s));
+            MD_HIP(hipMemcpy(h, sa.sync, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "shear debug: down polls %d spins %d immediate %d lead-sum %d | up polls %d spins %d immediate %d lead-sum %d | rows*strips %ld\n",
+                    h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], (long)pl.H * sa.nsh * batch);
+        }
     } else {
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
