@@ -547,8 +547,6 @@ struct ShearArgs {
     size_t strideHand;      // bytes per pair
     int* sync;              // [0] ticket (down) [1] ticket (up) [2] error, [16 + (sweep*B + pair)*nsh + k] progress
     int nsh, cmin, batch;
-    int debugNoWait;        // measurement only (results are wrong): bit0 skip neighbour waits, bit1 skip S stores,
-                            // bit2 skip H/S loads, bit3 skip the per-row barrier
 };
 constexpr int SHEAR_SPIN_LIMIT = 1 << 22;
 
@@ -604,7 +602,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
         const int* progNb = progMe + (UP ? -1 : 1);
         int* errWord = sa.sync + 2;
-        int seen = (sa.debugNoWait & 1) ? 0x7FFFFFFF : 0;
+        int seen = 0;
         // m = 15 sits in sheared column c0 + 15 (down) / c0 (up); m = 14 next to it
         const int c15 = UP ? c0 : c0 + CW - 1, c14 = UP ? c0 + 1 : c0 + CW - 2;
         // does this lane fetch a neighbour state for row i?
@@ -622,8 +620,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
             const int y = ys + sy * i;
             const int need = UP ? H - 1 - y : y;         // rows the neighbour must have published
             if (seen < need) {
-                int it = 0;
-                for (;; it++) {
+                for (int it = 0;; it++) {
                     seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (seen >= need) break;
                     if (it > SHEAR_SPIN_LIMIT || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -634,7 +631,6 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                     __builtin_amdgcn_s_sleep(2);
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                if ((sa.debugNoWait & 16) && lane == 0) { atomicAdd(&sa.sync[4 + (UP ? 4 : 0)], 1); atomicAdd(&sa.sync[5 + (UP ? 4 : 0)], it); if (it == 0) atomicAdd(&sa.sync[6 + (UP ? 4 : 0)], 1); atomicAdd(&sa.sync[7 + (UP ? 4 : 0)], seen - need); }
             }
             if (mine) w = hand_load(hand_slot(y - sy, nbk, which, lic));
         };
@@ -653,22 +649,27 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
             const int y = ys + sy * i;
             if (lane == 0) __hip_atomic_store(progMe, (UP ? H - 1 - y : y) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        // Software pipeline, one step per row and never waiting on an operation issued in the same
-        // step: step i drains what step i-1 issued (stores of row i-2, loads for row i+1), announces
-        // row i-2, parks row i+1's states in LDS, requests row i+2's and sends row i-1's.
+        // Software pipeline, one step per row, that never waits for an operation issued in the same
+        // step: step i first drains what step i-1 issued (stores of row i-2, loads for row i+1, a
+        // sample of the neighbour's progress), then announces row i-2, sends row i-1, parks row i+1's
+        // states in LDS and requests row i+2's.  The progress sample makes the request's own poll
+        // (which has to wait for its answer) the exception.
         uint4 w = make_uint4(0, 0, 0, 0);
         request(0, w);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         park(0, w);
         if (nrows > 1) request(1, w);
+        int sample = 0;
         __syncthreads();
         for (int i = 0; i < nrows; i++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            seen = max(seen, sample);
             if (i >= 2) announce(i - 2);
+            if (i >= 1) send(i - 1);
             if (i + 1 < nrows) park(i + 1, w);
             if (i + 2 < nrows) request(i + 2, w);
-            if (i >= 1) send(i - 1);
-            if (!(sa.debugNoWait & 8)) __syncthreads();
+            if (hasNb) sample = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
         }
         send(nrows - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -710,10 +711,8 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         if (x >= 0 && x < W) {
             load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
             const size_t pix = (size_t)y * W + x;
-            if (!(sa.debugNoWait & 4)) {
             hb = load16_stream(Hp + pix * 256 + lic * 16);
             if (UP) { if (S4B) sb = load16_stream(Sb + pix * 256 + lic * 16); else load8_stream(Sp + (pix * 256 + lic * DPL), Snext); }
-            }
         }
     };
     fetch_row(0);
@@ -768,9 +767,9 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                 }
                 store8(Sp + (pix * 256 + lic * DPL), nat);
             } else if (S4B) store16_stream(Sb + pix * 256 + lic * 16, pack_bytes(Sacc));
-            else if (!(sa.debugNoWait & 2)) store8_stream(Sp + (pix * 256 + lic * DPL), Sacc);
+            else store8_stream(Sp + (pix * 256 + lic * DPL), Sacc);
         }
-        if (!(sa.debugNoWait & 8)) __syncthreads();   // vs/bs[par] complete before the next row reads them
+        __syncthreads();   // vs/bs[par] complete before the next row reads them
     }
 }
 
@@ -896,7 +895,6 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         sa.hand = extra; sa.strideHand = bndBytes;
         sa.sync = (int*)(hbase + 2 * oneH * batch + oneRec * batch);
         sa.nsh = shear_strips(pl.H, pl.W); sa.cmin = -(pl.H - 1); sa.batch = batch;
-        sa.debugNoWait = getenv("MDISP_SHEAR_DEBUG") ? atoi(getenv("MDISP_SHEAR_DEBUG")) : 0;
         MD_HIP(hipMemsetAsync(sa.sync, 0, shear_sync_bytes(pl.H, pl.W, batch), s));
         if (errWord) *errWord = sa.sync + 2;
         dim3 gh((2 * pl.H + 15) / 16, batch), gs((unsigned)sa.nsh * batch);
@@ -913,13 +911,6 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
 #undef SGM2_SHEAR
         MD_HIP(hipGetLastError());
-        if (sa.debugNoWait & 16) {
-            int h[16];
-            MD_HIP(hipStreamSynchronize(s));
-            MD_HIP(hipMemcpy(h, sa.sync, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "shear debug: down polls %d spins %d immediate %d lead-sum %d | up polls %d spins %d immediate %d lead-sum %d | rows*strips %ld\n",
-                    h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], (long)pl.H * sa.nsh * batch);
-        }
     } else {
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \

@@ -4,6 +4,9 @@
 #include <stdio.h>
 typedef unsigned int u32;
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 ash(u32 v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ u32 hsu(h2 v) { return __builtin_bit_cast(u32, v); }
 __device__ __forceinline__ us2 asv(u32 v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ u32 asu(us2 v) { return __builtin_bit_cast(u32, v); }
 
@@ -27,6 +30,15 @@ __global__ __launch_bounds__(256) void k(u32* out, int iters, u32 seed)
                 if (OP == 6) a[i] = __builtin_amdgcn_perm(a[i], c, 0x05040100u) ^ (u32)i;          // v_perm_b32 (+xor)
                 if (OP == 7) a[i] = (a[i] & a[(i + 3) & 7]) | a[(i + 5) & 7];                                         // v_and_or
                 if (OP == 8) a[i] = min(a[i], a[(i + 3) & 7]) + 1;                                             // v_min_u32
+                if (OP == 9) a[i] = hsu(ash(a[i]) + ash(a[(i + 3) & 7]));                                       // v_pk_add_f16
+                if (OP == 10) a[i] = hsu(__builtin_elementwise_min(ash(a[i]), ash(a[(i + 3) & 7])));             // v_pk_min_f16
+                if (OP == 11) a[i] = __float_as_uint(__uint_as_float(a[i]) + __uint_as_float(a[(i + 3) & 7]));   // v_add_f32
+                if (OP == 12) a[i] = __float_as_uint(fminf(__uint_as_float(a[i]), __uint_as_float(a[(i + 3) & 7])));  // v_min_f32
+                if (OP == 13) a[i] = __float_as_uint(fmaf(__uint_as_float(a[i]), __uint_as_float(c), __uint_as_float(a[(i + 3) & 7])));  // v_fma_f32
+                if (OP == 14) a[i] = hsu(ash(a[i]) * ash(c) + ash(a[(i + 3) & 7]));                               // v_pk_fma_f16
+                if (OP == 15) a[i] = min(min(a[i], a[(i + 3) & 7]), a[(i + 5) & 7]);                              // v_min3_u32
+                if (OP == 16) a[i] = a[i] + a[(i + 3) & 7] + a[(i + 5) & 7];                                      // v_add3_u32
+                if (OP == 17) a[i] = asu(asv(a[i]) * asv(c) + asv(a[(i + 3) & 7]));                               // v_pk_mad_u16
             }
         }
     }
@@ -64,5 +76,14 @@ int main()
     run<6>("v_perm_b32 + v_xor", 2);
     run<7>("v_and_or_b32", 1);
     run<8>("v_min_u32 + v_add", 2);
+    run<9>("v_pk_add_f16", 1);
+    run<10>("v_pk_min_f16", 1);
+    run<11>("v_add_f32", 1);
+    run<12>("v_min_f32", 1);
+    run<13>("v_fma_f32", 1);
+    run<14>("v_pk_fma_f16", 1);
+    run<15>("v_min3_u32", 1);
+    run<16>("v_add3_u32", 1);
+    run<17>("v_pk_mad_u16", 1);
     return 0;
 }
