@@ -132,6 +132,13 @@ SGM_CASES = [
     (35, 49, 0, 80, 20, 300, 10, 1, 8, 1),      # path values above 255: 16-bit horizontal volumes
     (70, 33, 1, 256, 8, 32, 10, 2, 8, 1),
     (17, 16, 0, 32, 8, 32, 10, 1, 8, 1),
+    (45, 61, 0, 64, 10, 100, 10, 1, 8, 1),      # byte path states but 16-bit four-path partial sums
+    (150, 20, 0, 16, 8, 32, 10, 1, 8, 1),       # taller than wide: most sheared strips are partial
+    (40, 7, 0, 8, 8, 32, 10, 1, 8, 1),          # narrower than one strip
+    (3, 50, 0, 16, 8, 32, 10, 1, 8, 1),         # the smallest height the census frame allows
+    (64, 200, 0, 256, 8, 47, 10, 1, 8, 1),      # largest P2 with byte partial sums
+    (64, 200, 0, 256, 8, 48, 10, 1, 8, 1),      # smallest P2 without
+    (90, 310, 0, 128, 8, 247, 10, 1, 8, 1),     # largest P2 with byte path states
 ]
 
 
@@ -229,3 +236,17 @@ def test_sgm_volume_bit_exact(api, orc):
         S = api.sgbm_volume(L, R, api.sgbm_params(minD, D, P1, P2, 10, 1, 8, 1))
         _, E = orc.sgm(L, R, minD, D, P1, P2, 10, 1, 8, 1, want_S=True)
         assert np.array_equal(S, E)
+
+
+@pytest.mark.gpu
+def test_sgm_full_size_frame_bit_exact(api, orc):
+    # the benchmark configuration itself: 1920x1080, D = 256, P1 = 8, P2 = 32, 8 paths (oracle: about a second)
+    L, R, gt = api.synth_pair(0x5EED0001, 1080, 1920, 256)
+    p = api.sgbm_params(0, 256, 8, 32, 10, 1, 8, 1)
+    got = api.sgbm_compute(L, R, p)
+    exp = orc.sgm(L, R, 0, 256, 8, 32, 10, 1, 8, 1)
+    assert np.array_equal(got, exp)
+    # size-independent property: away from occlusions the planted disparity is recovered
+    valid = got >= 0
+    assert valid.mean() > 0.6
+    assert np.median(np.abs(got[valid] / 16.0 - gt[valid])) <= 1.0
