@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the "
+                                                      "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -71,10 +73,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()        # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from cameracalibration_amd import _lib, api, shard
     lib = _lib.load()
@@ -115,7 +122,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.slowest_rank_seconds(elapsed, dist if world > 1 else None, device="cuda")
+    elapsed = shard.slowest_rank_seconds(elapsed, dist if world > 1 else None,
+                                         device="cuda" if args.backend == "nccl" else "cpu")
 
     # per-pair device time of the hot path, HIP events on the stream the kernels run on
     _lib.check(lib.mdisp_enable_timing(ctx.handle, 1))
