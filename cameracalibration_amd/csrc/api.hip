@@ -39,7 +39,7 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->stage = nullptr; c->stage_bytes = 0;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -61,6 +61,7 @@ extern "C" void mdisp_destroy(mdisp_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->stage) (void)hipFree(c->stage);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -80,6 +81,51 @@ int md_check_sgm_error(mdisp_ctx* c)
     c->sgm_err = nullptr;
     MD_HIP(hipMemcpy(&flag, p, sizeof(int), hipMemcpyDeviceToHost));
     MD_REQUIRE(flag == 0, MDISP_E_HIP, "SGM sweep pipeline: a strip waited too long for its neighbour (results are invalid)");
+    return MDISP_OK;
+}
+
+static void* stage_buffer(mdisp_ctx* c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return c->stage;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { mdisp_set_error("stream sync failed"); return nullptr; }
+    if (c->stage) (void)hipFree(c->stage);
+    c->stage = nullptr; c->stage_bytes = 0;
+    const size_t want = md_align(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc(&c->stage, want) != hipSuccess) { mdisp_set_error("hipMalloc(%zu) failed for the copy staging buffer", want); return nullptr; }
+    c->stage_bytes = want;
+    return c->stage;
+}
+
+int md_h2d_2d(mdisp_ctx* c, void* d, size_t dpitch, const void* h, size_t hstep, size_t rowBytes, size_t rows)
+{
+    if (rows == 0 || rowBytes == 0) return MDISP_OK;
+    if (hstep == dpitch) {
+        MD_HIP(hipMemcpyAsync(d, h, (rows - 1) * dpitch + rowBytes, hipMemcpyHostToDevice, c->stream));
+    } else if (hstep == rowBytes) {
+        void* st = stage_buffer(c, rows * rowBytes);
+        if (!st) return MDISP_E_NOMEM;
+        MD_HIP(hipMemcpyAsync(st, h, rows * rowBytes, hipMemcpyHostToDevice, c->stream));
+        MD_HIP(hipMemcpy2DAsync(d, dpitch, st, rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        MD_HIP(hipMemcpy2DAsync(d, dpitch, h, hstep, rowBytes, rows, hipMemcpyHostToDevice, c->stream));
+    }
+    return MDISP_OK;
+}
+
+int md_d2h_2d(mdisp_ctx* c, void* h, size_t hstep, const void* d, size_t dpitch, size_t rowBytes, size_t rows)
+{
+    if (rows == 0 || rowBytes == 0) return MDISP_OK;
+    if (hstep == dpitch && hstep == rowBytes) {
+        MD_HIP(hipMemcpyAsync(h, d, rows * rowBytes, hipMemcpyDeviceToHost, c->stream));
+    } else if (hstep == rowBytes) {
+        void* st = stage_buffer(c, rows * rowBytes);
+        if (!st) return MDISP_E_NOMEM;
+        MD_HIP(hipMemcpy2DAsync(st, rowBytes, d, dpitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+        MD_HIP(hipMemcpyAsync(h, st, rows * rowBytes, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        // the caller's rows are padded: never write between them
+        MD_HIP(hipMemcpy2DAsync(h, hstep, d, dpitch, rowBytes, rows, hipMemcpyDeviceToHost, c->stream));
+    }
     return MDISP_OK;
 }
 
@@ -161,11 +207,11 @@ static int upload_gray(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch
 {
     MD_REQUIRE(im->depth == MDISP_8U, MDISP_E_UNSUPPORTED, "only CV_8U images are supported (got depth %d)", im->depth);
     if (im->channels == 1) {
-        MD_HIP(hipMemcpy2DAsync(d, dpitch, im->data, im->step_bytes, im->cols, im->rows, hipMemcpyHostToDevice, c->stream));
+        MD_TRY(md_h2d_2d(c, d, dpitch, im->data, im->step_bytes, im->cols, im->rows));
         return MDISP_OK;
     }
     MD_REQUIRE(im->channels == 3, MDISP_E_UNSUPPORTED, "only 1- or 3-channel images are supported");
-    MD_HIP(hipMemcpy2DAsync(stage, stage_pitch, im->data, im->step_bytes, (size_t)im->cols * 3, im->rows, hipMemcpyHostToDevice, c->stream));
+    MD_TRY(md_h2d_2d(c, stage, stage_pitch, im->data, im->step_bytes, (size_t)im->cols * 3, im->rows));
     return md_bgr2gray(c->stream, stage, stage_pitch, im->rows, im->cols, d, dpitch);
 }
 
@@ -195,7 +241,7 @@ extern "C" int mdisp_census_transform(mdisp_ctx* c, const mdisp_image* src, int 
     if (!base) return MDISP_E_NOMEM;
     if ((rc = upload_gray(c, src, base + o_src, pitch, base + o_stage, p3))) return rc;
     if ((rc = md_census(c->stream, base + o_src, pitch, H, W, method, arg, base + o_dst, pitch, base + o_scr))) return rc;
-    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_dst, pitch, W, H, hipMemcpyDeviceToHost, c->stream));
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + o_dst, pitch, W, H));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
 }
@@ -215,10 +261,10 @@ extern "C" int mdisp_hamming_dist(mdisp_ctx* c, const mdisp_image* a, const mdis
     size_t o_a = cv.take(pitch * H), o_b = cv.take(pitch * H), o_d = cv.take(p4 * H);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
-    MD_HIP(hipMemcpy2DAsync(base + o_a, pitch, a->data, a->step_bytes, W, H, hipMemcpyHostToDevice, c->stream));
-    MD_HIP(hipMemcpy2DAsync(base + o_b, pitch, b->data, b->step_bytes, W, H, hipMemcpyHostToDevice, c->stream));
+    MD_TRY(md_h2d_2d(c, base + o_a, pitch, a->data, a->step_bytes, W, H));
+    MD_TRY(md_h2d_2d(c, base + o_b, pitch, b->data, b->step_bytes, W, H));
     if ((rc = md_hamming(c->stream, base + o_a, pitch, base + o_b, pitch, H, W, (int32_t*)(base + o_d), p4))) return rc;
-    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_d, p4, (size_t)W * 4, H, hipMemcpyDeviceToHost, c->stream));
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + o_d, p4, (size_t)W * 4, H));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
 }
@@ -319,7 +365,7 @@ extern "C" int mdisp_census_stereo(mdisp_ctx* c, const mdisp_image* L, const mdi
     // census rows are read as dwords: the census of `ref` uses the padded-width pitch as well
     if ((rc = census_stereo_body(c, b.ref, b.other, b.pitchW, H, W, p, census_method, agg_mode, b.pad, b.pitchP, b.cRef,
                                  b.pitchP, b.cPad, b.scr, (double*)b.out, b.extra))) return rc;
-    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, (size_t)W * 8, (size_t)W * 8, H, hipMemcpyDeviceToHost, c->stream));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, b.out, (size_t)W * 8, (size_t)W * 8, H));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
 }
@@ -367,7 +413,7 @@ static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     else rc = md_cost_box_wta(s, b.ref, b.pitchW, b.pad, b.pitchP, H, W, minD, maxD, off0, offStep, p->winSize,
                               MD_COST_ABSDIFF_SQR, MD_OUT_U8, b.out, opitch);
     if (rc) return rc;
-    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, opitch, W, H, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, b.out, opitch, W, H));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }
@@ -410,7 +456,7 @@ extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
     }
     if ((rc = md_gif_stereo(c, b.extra, b.ref, b.pitchW, H, W, D, minD, p->winSize, eps, gif_type, r2, namda, cr, crp, cp, cpp,
                             off0, offStep, kind, cost_source == MDISP_COST_VOLUME ? costs : nullptr, 0, (float*)b.out, nullptr))) return rc;
-    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, b.out, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, b.out, (size_t)W * 4, (size_t)W * 4, H));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }
@@ -478,7 +524,7 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
     if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
     if ((rc = md_sgm_run(c, pl, base + o_l, base + o_r, pitch, 0, (int16_t*)(base + o_d), base + o_ws))) return rc;
-    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H, hipMemcpyDeviceToHost, c->stream));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H));
     MD_HIP(hipStreamSynchronize(c->stream));
     return md_check_sgm_error(c);
 }
@@ -502,7 +548,7 @@ extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp
     if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
     const u16* S;
     if ((rc = md_sgm_aggregate_only(c, pl, base + o_l, base + o_r, pitch, base + o_ws, &S))) return rc;
-    MD_HIP(hipMemcpy2DAsync(Sh, (size_t)pl.D * 2, S, (size_t)pl.sstride * 2, (size_t)pl.D * 2, (size_t)H * W, hipMemcpyDeviceToHost, c->stream));
+    MD_TRY(md_d2h_2d(c, Sh, (size_t)pl.D * 2, S, (size_t)pl.sstride * 2, (size_t)pl.D * 2, (size_t)H * W));
     MD_HIP(hipStreamSynchronize(c->stream));
     return md_check_sgm_error(c);
 }
@@ -526,11 +572,11 @@ extern "C" int mdisp_lr_check(mdisp_ctx* c, const mdisp_image* dL, const mdisp_i
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     hipStream_t s = c->stream;
-    MD_HIP(hipMemcpy2DAsync(base + o_l, (size_t)W * 4, dL->data, dL->step_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
-    MD_HIP(hipMemcpy2DAsync(base + o_r, (size_t)W * 4, dR->data, dR->step_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
+    MD_TRY(md_h2d_2d(c, base + o_l, (size_t)W * 4, dL->data, dL->step_bytes, (size_t)W * 4, H));
+    MD_TRY(md_h2d_2d(c, base + o_r, (size_t)W * 4, dR->data, dR->step_bytes, (size_t)W * 4, H));
     if ((rc = md_lr_check(s, (float*)(base + o_l), (float*)(base + o_r), H, W, thresh, base + o_vl, base + o_vr))) return rc;
-    MD_HIP(hipMemcpy2DAsync(validL->data, validL->step_bytes, base + o_vl, W, W, H, hipMemcpyDeviceToHost, s));
-    MD_HIP(hipMemcpy2DAsync(validR->data, validR->step_bytes, base + o_vr, W, W, H, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, validL->data, validL->step_bytes, base + o_vl, W, W, H));
+    MD_TRY(md_d2h_2d(c, validR->data, validR->step_bytes, base + o_vr, W, W, H));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }
@@ -550,11 +596,11 @@ extern "C" int mdisp_remap(mdisp_ctx* c, const mdisp_image* src, const int16_t* 
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     hipStream_t s = c->stream;
-    MD_HIP(hipMemcpy2DAsync(base + o_s, sp, src->data, src->step_bytes, (size_t)sW * cn, sH, hipMemcpyHostToDevice, s));
+    MD_TRY(md_h2d_2d(c, base + o_s, sp, src->data, src->step_bytes, (size_t)sW * cn, sH));
     MD_HIP(hipMemcpyAsync(base + o_m1, map1, (size_t)dH * dW * 4, hipMemcpyHostToDevice, s));
     MD_HIP(hipMemcpyAsync(base + o_m2, map2, (size_t)dH * dW * 2, hipMemcpyHostToDevice, s));
     if ((rc = md_remap(s, base + o_s, sp, sH, sW, cn, (const int16_t*)(base + o_m1), (const u16*)(base + o_m2), dH, dW, base + o_d, dp))) return rc;
-    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, base + o_d, dp, (size_t)dW * cn, dH, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + o_d, dp, (size_t)dW * cn, dH));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }

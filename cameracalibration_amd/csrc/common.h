@@ -30,6 +30,12 @@ void mdisp_set_error(const char* fmt, ...);
         }                                            \
     } while (0)
 
+#define MD_TRY(expr)                 \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__) return rc__;       \
+    } while (0)
+
 struct mdisp_ctx {
     int device;
     hipStream_t stream;
@@ -39,10 +45,19 @@ struct mdisp_ctx {
     bool timing;
     hipEvent_t ev[6];    // [0,1] whole call, [2,3] SGM aggregation, [4,5] separate WTA kernel
     bool ev_valid[3];
+    void* stage;         // grow-only device staging buffer of the host<->device image copies
+    size_t stage_bytes;
     const int* sgm_err;  // device error word of the last pipelined SGM call (0 = fine), or null
 };
 // after the stream has been synchronised: fails if the last SGM call reported a hand-off timeout
 int md_check_sgm_error(mdisp_ctx* ctx);
+
+// Image copies between host memory (row stride hstep) and pitched device memory, enqueued on the
+// context's stream.  A 2-D copy from pageable host memory is executed row by row by the runtime
+// (milliseconds for a VGA image); contiguous host images therefore travel as ONE linear copy to or
+// from a device staging buffer plus a device-side 2-D copy.
+int md_h2d_2d(mdisp_ctx* c, void* d, size_t dpitch, const void* h, size_t hstep, size_t rowBytes, size_t rows);
+int md_d2h_2d(mdisp_ctx* c, void* h, size_t hstep, const void* d, size_t dpitch, size_t rowBytes, size_t rows);
 
 // grow-only workspace; returns nullptr on failure (error set)
 void* mdisp_ws(mdisp_ctx* ctx, size_t bytes);

@@ -663,9 +663,9 @@ extern "C" int mdisp_steer_filter(mdisp_ctx* c, const mdisp_image* src, mdisp_im
     SteerTaps* taps = cv.take<SteerTaps>(1);
     unsigned long long* mb = cv.take<unsigned long long>(1);
     hipStream_t s = c->stream;
-    MD_HIP(hipMemcpy2DAsync(dS, pitch, src->data, src->step_bytes, W, H, hipMemcpyHostToDevice, s));
+    MD_TRY(md_h2d_2d(c, dS, pitch, src->data, src->step_bytes, W, H));
     if ((rc = steer_run(s, dS, pitch, H, W, O, mb, taps, out, nullptr))) return rc;
-    MD_HIP(hipMemcpy2DAsync(dst->data, dst->step_bytes, out, (size_t)W * 8, (size_t)W * 8, H, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, out, (size_t)W * 8, (size_t)W * 8, H));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }
@@ -699,11 +699,11 @@ extern "C" int mdisp_guided_filter(mdisp_ctx* c, const mdisp_image* guide, const
     u8* rawP = (u8*)cv.take<double>(N);      // raw input slice, any supported depth
     float* dOut = cv.take<float>(N); float* dBeta = cv.take<float>(N);
     hipStream_t s = c->stream;
-    MD_HIP(hipMemcpy2DAsync(dG, pitch, guide->data, guide->step_bytes, W, H, hipMemcpyHostToDevice, s));
+    MD_TRY(md_h2d_2d(c, dG, pitch, guide->data, guide->step_bytes, W, H));
     if (gif_type == MDISP_SKWGIF)
-        MD_HIP(hipMemcpy2DAsync(dSteer, (size_t)W * 8, steerW->data, steerW->step_bytes, (size_t)W * 8, H, hipMemcpyHostToDevice, s));
+        MD_TRY(md_h2d_2d(c, dSteer, (size_t)W * 8, steerW->data, steerW->step_bytes, (size_t)W * 8, H));
     const size_t esz = P->depth == MDISP_8U ? 1 : 4;
-    MD_HIP(hipMemcpy2DAsync(rawP, (size_t)W * esz, P->data, P->step_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, s));
+    MD_TRY(md_h2d_2d(c, rawP, (size_t)W * esz, P->data, P->step_bytes, (size_t)W * esz, H));
     GuideState gs;
     if ((rc = guide_prepare(c, dG, pitch, H, W, r, r2, gif_type, eps, namuda, dSteer, sc, gs, cv))) return rc;
     // normalise the slice (gifs.cpp:56)
@@ -726,8 +726,8 @@ extern "C" int mdisp_guided_filter(mdisp_ctx* c, const mdisp_image* guide, const
     oa.best = nullptr; oa.disp32 = nullptr; oa.disp64 = nullptr; oa.d0 = 0; oa.first = 1;
     out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
     MD_HIP(hipGetLastError());
-    MD_HIP(hipMemcpy2DAsync(out->data, out->step_bytes, dOut, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
-    if (beta) MD_HIP(hipMemcpy2DAsync(beta->data, beta->step_bytes, dBeta, (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, s));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, dOut, (size_t)W * 4, (size_t)W * 4, H));
+    if (beta) MD_TRY(md_d2h_2d(c, beta->data, beta->step_bytes, dBeta, (size_t)W * 4, (size_t)W * 4, H));
     MD_HIP(hipStreamSynchronize(s));
     return MDISP_OK;
 }

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Throughput of the non-SGM paths (for the design notes; bench.py reports the SGM configuration only).
+census + box + WTA (640x480, D=64, device-resident) and the guided-filter aggregations through the host API."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cameracalibration_amd import _lib, api  # noqa: E402
+
+lib = _lib.load()
+ctx = _lib.Context(stream=torch.cuda.current_stream().cuda_stream)
+
+
+def dev_rate(H, W, D, win, agg, n=50):
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((H, W), dtype=torch.float64, device="cuda")
+    p = _lib.mdisp_param(win, 0, D - 1, 1)
+
+    def call():
+        _lib.check(lib.mdisp_census_stereo_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), H, W, W, C.byref(p), api.BASIC_CENSUS, agg,
+                                               out.data_ptr()))
+    call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return dt, H * W * D / dt / 1e6
+
+
+def host_rate(fn, H, W, D, n=3):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    dt = (time.perf_counter() - t0) / n
+    return dt, H * W * D / dt / 1e6
+
+
+for (H, W, D, win) in ((480, 640, 64, 7), (1080, 1920, 256, 7)):
+    dt, r = dev_rate(H, W, D, win, api.AGG_BOX)
+    print(f"census+box{win}+WTA  {W}x{H} D={D} device-resident: {dt*1e3:.3f} ms  {r:.0f} Mdisp/s")
+    dt, r = dev_rate(H, W, D, win, api.AGG_GUIDED, n=5)
+    print(f"census+guided{win}+WTA {W}x{H} D={D} device-resident: {dt*1e3:.3f} ms  {r:.0f} Mdisp/s")
+H, W, D = 480, 640, 64
+L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=7, minDisparity=0, maxDisparity=D - 1, isDispLeft=True)
+for name, gif in (("GIF", api.GIF), ("EGIF", api.EGIF), ("SKWGIF", api.SKWGIF)):
+    dt, r = host_rate(lambda: api.asw_gifs(p, 0.01, gif, 15, 0.1, 0.5, api.COST_CENSUS), H, W, D)
+    print(f"asw_gifs {name:7s} {W}x{H} D={D} host API (copies included): {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
+dt, r = host_rate(lambda: api.computeSAD_BFOpti(p), H, W, D)
+print(f"computeSAD_BFOpti  {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
+dt, r = host_rate(lambda: api.computeSAD_inteOpti(p), H, W, D)
+print(f"computeSAD_inteOpti {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
