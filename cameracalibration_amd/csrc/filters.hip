@@ -71,18 +71,62 @@ __device__ __forceinline__ int raw_cost(const CostSrc& c, int x, int y, int k)
     return r > p ? r - p : p - r;
 }
 
-// min/max of integer cost slices k0 .. k0+n-1 computed on the fly
-__global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, u32* mm)
+// min/max of integer cost slices k0 .. k0+n-1 computed on the fly.  A workgroup owns a tile of
+// 256 columns x MM_ROWS rows and walks the slices with the tile's reference pixels in registers, so
+// each census / gray byte is fetched once and the shifted operand rows stay in cache.
+#define MM_ROWS 16
+__global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, int n, u32* __restrict__ part)
 {
-    const int k = blockIdx.y;
-    u32 lo = 0xFFFFFFFFu, hi = 0u;
-    const size_t N = (size_t)c.W * c.H;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / c.W), x = (int)(i - (size_t)y * c.W);
-        u32 o = f2ord((float)raw_cost(c, x, y, k0 + k));
-        lo = min(lo, o); hi = max(hi, o);
+    __shared__ u32 slo[4], shi[4];
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * MM_ROWS;
+    const bool inx = x < c.W;
+    const int rows = min(MM_ROWS, c.H - y0);
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    int ref[MM_ROWS];
+#pragma unroll
+    for (int j = 0; j < MM_ROWS; j++) ref[j] = (inx && j < rows) ? c.ref[(size_t)(y0 + j) * c.rp + x] : 0;
+    for (int k = 0; k < n; k++) {
+        int lo = 0x7FFFFFFF, hi = -1;
+        if (inx) {
+            const u8* p = c.pad + (size_t)y0 * c.pp + x + c.off0 + (k0 + k) * c.offStep;
+#pragma unroll
+            for (int j = 0; j < MM_ROWS; j++) {
+                if (j < rows) {
+                    const int pv = p[(size_t)j * c.pp];
+                    const int v = c.kind == MD_COST_HAMMING ? __popc((u32)(ref[j] ^ pv)) : abs(ref[j] - pv);
+                    lo = min(lo, v); hi = max(hi, v);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { lo = min(lo, __shfl_xor(lo, m, 64)); hi = max(hi, __shfl_xor(hi, m, 64)); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = (u32)lo; shi[threadIdx.x >> 6] = (u32)(hi + 1); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // per-workgroup partial: min as is, max + 1 so that 0 means "no pixel"
+            part[((size_t)wg * n + k) * 2] = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
+            part[((size_t)wg * n + k) * 2 + 1] = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+        }
     }
-    block_minmax_commit(lo, hi, mm + 2 * k);
+}
+// combine the partials of all workgroups; costs are small non-negative integers, whose float
+// images order like the integers
+__global__ __launch_bounds__(256) void cost_minmax_finish_kernel(const u32* __restrict__ part, int nwg, int n, u32* mm)
+{
+    __shared__ u32 slo[256], shi[256];
+    const int k = blockIdx.x;
+    u32 lo = 0x7FFFFFFFu, hi = 0u;
+    for (int w = threadIdx.x; w < nwg; w += 256) {
+        lo = min(lo, part[((size_t)w * n + k) * 2]); hi = max(hi, part[((size_t)w * n + k) * 2 + 1]);
+    }
+    slo[threadIdx.x] = lo; shi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { slo[threadIdx.x] = min(slo[threadIdx.x], slo[threadIdx.x + o]); shi[threadIdx.x] = max(shi[threadIdx.x], shi[threadIdx.x + o]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && shi[0] > 0) { mm[2 * k] = f2ord((float)slo[0]); mm[2 * k + 1] = f2ord((float)(shi[0] - 1)); }
 }
 
 // convertTo(dst, CV_32F, scale, shift): float arithmetic for 8U / 32F sources, double for 32S
@@ -123,17 +167,6 @@ __global__ __launch_bounds__(256) void minmax_u8_image_kernel(const u8* __restri
             lo = min(lo, o); hi = max(hi, o);
         }
     block_minmax_commit(lo, hi, mm);
-}
-
-__global__ __launch_bounds__(256) void cost_normalize_kernel(CostSrc c, int k0, const u32* mm, int mode, float* __restrict__ dst)
-{
-    const int k = blockIdx.y;
-    const u32 lo = mm[2 * k], hi = mm[2 * k + 1];
-    const size_t N = (size_t)c.W * c.H;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / c.W), x = (int)(i - (size_t)y * c.W);
-        dst[(size_t)k * N + i] = norm_apply((float)raw_cost(c, x, y, k0 + k), lo, hi, mode);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -300,6 +333,7 @@ __global__ __launch_bounds__(256) void ab_kernel(float* __restrict__ meanP_b, fl
 // beta = a_bar / (1 - a_bar) (gifs.cpp:261); optional first-minimum WTA over the n slices of the
 // batch against the running best (strict '<': methods_disp.cpp:1287, minMaxLoc at :996).
 struct OutArgs {
+    const float* v;                                       // filtered slices (a_bar*G + b_bar), or null to form them here
     const float* abar; const float* bbar; const float* G; size_t N; int n;
     float* filtered; float* beta;
     float* best; float* disp32; double* disp64; int d0;   // d0 = disparity of the batch's first slice
@@ -309,15 +343,19 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
-    const float g = a.G[i];
+    const float g = a.v ? 0.f : a.G[i];
     float best = 0.f; int bestd = 0; bool have = false;
     if (a.best && !a.first) { best = a.best[i]; have = true; bestd = a.disp32 ? (int)a.disp32[i] : (int)a.disp64[i]; }
     for (int k = 0; k < a.n; k++) {
         const size_t o = (size_t)k * a.N + i;
-        const float ab = a.abar[o];
-        const float v = __fadd_rn(__fmul_rn(ab, g), a.bbar[o]);
-        if (a.filtered) a.filtered[o] = v;
-        if (a.beta) a.beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
+        float v;
+        if (a.v) v = a.v[o];
+        else {
+            const float ab = a.abar[o];
+            v = __fadd_rn(__fmul_rn(ab, g), a.bbar[o]);
+            if (a.filtered) a.filtered[o] = v;
+            if (a.beta) a.beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
+        }
         if (a.best) {
             if (!have || v < best) { best = v; bestd = a.d0 + k; have = true; }
         }
@@ -327,6 +365,238 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
         if (a.disp32) a.disp32[i] = (float)bestd;
         if (a.disp64) a.disp64[i] = (double)bestd;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused separable box filter of TWO quantities at once, marching down the image: a workgroup owns
+// MW columns of a row band; every input row is loaded once into LDS (with its horizontal halo),
+// each thread forms the horizontal window sums of its column in double, keeps them in an LDS ring
+// of `taps` rows and maintains the vertical running sums in registers (add the newest row, emit,
+// subtract the oldest -- the order of cv::boxFilter's ColumnSum).  The window sums never travel
+// through HBM, and the element-wise stage that follows the filter in the guided filter (a, b from
+// the means; a_bar*G + b_bar from the second pair of means) runs in the store functor.
+// Window: starts at p - ksz/2; mode 0: ksz taps, BORDER_REFLECT_101; mode 1: 2*(ksz/2) taps, zero
+// outside [0, n-1) (the clipped half-open window of getGuidedFilter_skwgif2, gifs.cpp:591-592).
+#define MW 128
+struct MarchGeom { int H, W, ksz, mode, band; };
+
+template <typename RingT, class Load, class Store>
+__global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld, Store st)
+{
+    extern __shared__ unsigned char march_smem[];
+    const int H = g.H, W = g.W;
+    const int a = g.ksz / 2;
+    const int taps = g.mode == 0 ? g.ksz : 2 * a;
+    const int rowW = MW + taps - 1, rowPad = (rowW + 3) & ~3;
+    float* row0 = reinterpret_cast<float*>(march_smem);
+    float* row1 = row0 + rowPad;
+    RingT* ring0 = reinterpret_cast<RingT*>(row1 + rowPad + (rowPad & 1 ? 1 : 0));
+    RingT* ring1 = ring0 + (size_t)taps * MW;
+    const int x0 = blockIdx.x * MW, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
+    const int tx = threadIdx.x, x = x0 + tx;
+    ld.begin(k);
+    double c0 = 0.0, c1 = 0.0;
+    const int nin = (y1 - y0) + taps - 1;
+    for (int j = 0; j < nin; j++) {
+        const int yy = y0 - a + j;
+        int ys = yy; bool rowValid = true;
+        if (g.mode == 0) ys = r101(yy, H); else rowValid = yy >= 0 && yy < H - 1;
+        __syncthreads();                       // the previous row's window sums are done with row0/row1
+        if (rowValid) {
+            for (int i = tx; i < rowW; i += MW) {
+                int xs = x0 - a + i; float q0 = 0.f, q1 = 0.f;
+                if (g.mode == 0) { xs = r101(xs, W); ld(xs, ys, k, q0, q1); }
+                else if (xs >= 0 && xs < W - 1) ld(xs, ys, k, q0, q1);
+                row0[i] = q0; row1[i] = q1;
+            }
+        }
+        __syncthreads();
+        double h0 = 0.0, h1 = 0.0;
+        if (rowValid) {
+            for (int i = 0; i < taps; i++) { h0 += (double)row0[tx + i]; h1 += (double)row1[tx + i]; }
+        }
+        const RingT r0 = (RingT)h0, r1 = (RingT)h1;
+        const int slot = j % taps;
+        ring0[(size_t)slot * MW + tx] = r0; ring1[(size_t)slot * MW + tx] = r1;
+        c0 += (double)r0; c1 += (double)r1;
+        if (j >= taps - 1) {
+            const int y = y0 + j - (taps - 1);
+            if (x < W) st(x, y, k, c0, c1);
+            const int os = (j + 1) % taps;     // the oldest row of the window just emitted
+            c0 -= (double)ring0[(size_t)os * MW + tx]; c1 -= (double)ring1[(size_t)os * MW + tx];
+        }
+    }
+}
+
+// Same filter for the common small odd windows (mode 0, TAPS = ksz in {3,5,7,9}): one wave per
+// workgroup, two columns per lane, and the ring of horizontal sums lives in registers (the row loop
+// is unrolled TAPS times so that ring slots are compile-time indices).  No LDS ring means occupancy
+// is set by registers, and the only LDS traffic is the current input row.
+#define MWF 128   // columns per wave
+template <int TAPS, class Load, class Store>
+__global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, Load ld, Store st)
+{
+    constexpr int A = TAPS / 2, ROWW = MWF + TAPS - 1, ROWP = (ROWW + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float row0[ROWP];
+    __shared__ __attribute__((aligned(16))) float row1[ROWP];
+    const int H = g.H, W = g.W;
+    const int x0 = blockIdx.x * MWF, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
+    const int lane = threadIdx.x, c0 = 2 * lane, x = x0 + c0;
+    ld.begin(k);
+    // source columns of the (at most three) row elements this lane loads, reflected once
+    constexpr int NLD = (ROWW + 63) / 64;
+    int xsrc[NLD];
+#pragma unroll
+    for (int e = 0; e < NLD; e++) xsrc[e] = r101(x0 - A + lane + 64 * e, W);
+    double ring[TAPS][4];               // [slot][quantity*2 + column]
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    const int nin = (y1 - y0) + TAPS - 1;
+    for (int j0 = 0; j0 < nin; j0 += TAPS) {
+#pragma unroll
+        for (int u = 0; u < TAPS; u++) {
+            const int j = j0 + u;
+            if (j < nin) {
+                const int ys = r101(y0 - A + j, H);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < NLD; e++) {
+                    const int i = lane + 64 * e;
+                    if (i < ROWW) {
+                        float q0, q1;
+                        ld(xsrc[e], ys, k, q0, q1);
+                        row0[i] = q0; row1[i] = q1;
+                    }
+                }
+                __syncthreads();
+                double h[4];
+                {
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < TAPS; i++) { a0 += (double)row0[c0 + i]; a1 += (double)row1[c0 + i]; }
+                    h[0] = a0; h[1] = a0 - (double)row0[c0] + (double)row0[c0 + TAPS];
+                    h[2] = a1; h[3] = a1 - (double)row1[c0] + (double)row1[c0 + TAPS];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ring[u][q] = h[q]; cs[q] += h[q]; }
+                if (j >= TAPS - 1) {
+                    const int y = y0 + j - (TAPS - 1);
+                    if (x < W) st(x, y, k, cs[0], cs[2]);
+                    if (x + 1 < W) st(x + 1, y, k, cs[1], cs[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cs[q] -= ring[(u + 1) % TAPS][q];
+                }
+            }
+        }
+    }
+}
+
+struct NormScale { float scale, shift; double dscale, dshift; };
+__device__ __forceinline__ NormScale norm_scale(u32 olo, u32 ohi)
+{
+    const double smin = (double)ord2f(olo), smax = (double)ord2f(ohi);
+    NormScale n;
+    n.dscale = (smax - smin > DBL_EPSILON) ? 1.0 / (smax - smin) : 0.0;
+    n.dshift = 0.0 - smin * n.dscale;
+    n.scale = (float)n.dscale; n.shift = (float)n.dshift;
+    return n;
+}
+
+// P = normalised integer cost computed on the fly; (P, G*P)
+struct LoadCostGP {
+    CostSrc c; int k0; const u32* mm; int mode; const float* G;
+    NormScale ns;
+    __device__ void begin(int k) { ns = norm_scale(mm[2 * k], mm[2 * k + 1]); }
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    {
+        const float v = (float)raw_cost(c, x, y, k0 + k);
+        const float P = mode == NORM_DOUBLE ? (float)((double)v * ns.dscale + ns.dshift) : __fadd_rn(__fmul_rn(v, ns.scale), ns.shift);
+        q0 = P; q1 = __fmul_rn(P, G[(size_t)y * c.W + x]);
+    }
+};
+// P = already normalised planar slices; (P, G*P)
+struct LoadPlanarGP {
+    const float* P; size_t N; int W; const float* G;
+    __device__ void begin(int) {}
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    {
+        const size_t i = (size_t)y * W + x;
+        const float p = P[(size_t)k * N + i];
+        q0 = p; q1 = __fmul_rn(p, G[i]);
+    }
+};
+// (a, b), optionally both times the steer weight
+struct LoadAB {
+    const float* A; const float* B; size_t N; int W; const float* w;
+    __device__ void begin(int) {}
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    {
+        const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
+        q0 = A[o]; q1 = B[o];
+        if (w) { const float ww = w[i]; q0 = __fmul_rn(q0, ww); q1 = __fmul_rn(q1, ww); }
+    }
+};
+// means of P and G*P -> a = (corrGP - meanG*meanP) / den, b = meanP - a*meanG   (gifs.cpp:96,127-128)
+struct StoreAB {
+    float* A; float* B; size_t N; int W; const float* meanG; const float* den; double scale;
+    __device__ void operator()(int x, int y, int k, double s0, double s1) const
+    {
+        const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
+        const float mp = (float)(s0 * scale), cr = (float)(s1 * scale), mg = meanG[i];
+        const float cov = __fsub_rn(cr, __fmul_rn(mg, mp));
+        const float a = __fdiv_rn(cov, den[i]);
+        A[o] = a; B[o] = __fsub_rn(mp, __fmul_rn(a, mg));
+    }
+};
+// means of a and b -> filtered value a_bar*G + b_bar (gifs.cpp:133), optionally beta = a_bar/(1-a_bar) (:261)
+struct StoreOut {
+    float* V; size_t N; int W; const float* G; double scale; const double* div; float* beta;
+    __device__ void operator()(int x, int y, int k, double s0, double s1) const
+    {
+        const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
+        float ab, bb;
+        if (div) { const double d = div[i]; ab = (float)(s0 * 1.0 / d); bb = (float)(s1 * 1.0 / d); }
+        else { ab = (float)(s0 * scale); bb = (float)(s1 * scale); }
+        V[o] = __fadd_rn(__fmul_rn(ab, G[i]), bb);
+        if (beta) beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
+    }
+};
+
+static bool march_supported(int ksz) { return ksz >= 1 && ksz <= 75; }   // ring of 2*ksz*128 doubles within 160 KB of LDS
+
+template <class Load, class Store>
+static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode, const Load& ld, const Store& st)
+{
+    const int taps = mode == 0 ? ksz : 2 * (ksz / 2);
+    if (taps < 1) { mdisp_set_error("window %d too small", ksz); return MDISP_E_BADARG; }
+    MarchGeom g;
+    g.H = H; g.W = W; g.ksz = ksz; g.mode = mode;
+    g.band = ksz <= 9 ? 64 : (ksz <= 21 ? 128 : 256);
+    if (mode == 0 && (ksz == 3 || ksz == 5 || ksz == 7 || ksz == 9)) {
+        dim3 grid((W + MWF - 1) / MWF, (H + g.band - 1) / g.band, n);
+        switch (ksz) {
+        case 3: dual_box_march_small_kernel<3, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
+        case 5: dual_box_march_small_kernel<5, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
+        case 7: dual_box_march_small_kernel<7, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
+        default: dual_box_march_small_kernel<9, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
+        }
+        MD_HIP(hipGetLastError());
+        return MDISP_OK;
+    }
+    const int rowW = MW + taps - 1, rowPad = (rowW + 3) & ~3;
+    dim3 grid((W + MW - 1) / MW, (H + g.band - 1) / g.band, n);
+    // the ring stays in double so that the window sums of float inputs are exact whatever the order
+    const size_t lds = (size_t)(2 * rowPad + 2) * sizeof(float) + 2 * (size_t)taps * MW * sizeof(double);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_box_march_kernel<double, Load, Store>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    dual_box_march_kernel<double, Load, Store><<<grid, MW, lds, s>>>(g, ld, st);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -587,29 +857,35 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
     return MDISP_OK;
 }
 
-// filter n normalised slices held in sc.F0; leaves a_bar in F1 and b_bar in F2
-static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, int n)
+// Filter n slices and leave the filtered values a_bar*G + b_bar in sc.F0.  The slices come either
+// normalised and planar in sc.F0 (cs == null) or as integer costs formed on the fly (cs != null,
+// normalised with the per-slice min/max in mm).  beta (nullable): a_bar/(1 - a_bar) of each slice.
+static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, int n, const CostSrc* cs, int k0, const u32* mm,
+                            int normMode, float* beta)
 {
     hipStream_t s = c->stream;
     const int H = gs.H, W = gs.W, r = gs.r;
     const size_t N = (size_t)H * W;
+    const bool skw = gs.type == MDISP_SKWGIF;
     int rc;
-    // meanP -> F1, corrGP -> F2   (gifs.cpp:60-61,71)
-    if ((rc = box_f32(s, sc.F0, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F1))) return rc;
-    if ((rc = box_f32(s, sc.F0, N, gs.G, 0, n, H, W, r, 0, sc.T, nullptr, sc.F2))) return rc;
-    // a -> F2, b -> F1
-    ab_kernel<<<dim3(nblk(N), n), 256, 0, s>>>(sc.F1, sc.F2, gs.meanG, gs.den, N);
-    if (gs.type == MDISP_SKWGIF) {
-        // steer-weighted means: boxsum(w*a)/boxsum(w) over the clipped window (gifs.cpp:587-611)
-        if ((rc = box_f32(s, sc.F2, N, gs.w, 0, n, H, W, gs.r2, 1, sc.T, gs.wsum, sc.F0))) return rc;   // a_bar -> F0
-        if ((rc = box_f32(s, sc.F1, N, gs.w, 0, n, H, W, gs.r2, 1, sc.T, gs.wsum, sc.F2))) return rc;   // b_bar -> F2
-        float* t = sc.F1; sc.F1 = sc.F0; sc.F0 = t;   // a_bar now in F1
-    } else {
-        if ((rc = box_f32(s, sc.F2, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F0))) return rc;    // a_bar -> F0
-        if ((rc = box_f32(s, sc.F1, N, nullptr, 0, n, H, W, r, 0, sc.T, nullptr, sc.F2))) return rc;    // b_bar -> F2
-        float* t = sc.F1; sc.F1 = sc.F0; sc.F0 = t;
+    if (!march_supported(r) || (skw && !march_supported(gs.r2))) {
+        mdisp_set_error("guided-filter window above 75 is not supported");
+        return MDISP_E_UNSUPPORTED;
     }
-    MD_HIP(hipGetLastError());
+    // (P, G*P) -> means -> a -> F1, b -> F2   (gifs.cpp:60-61,71,96,127-128)
+    StoreAB sab{sc.F1, sc.F2, N, W, gs.meanG, gs.den, 1.0 / ((double)r * r)};
+    if (cs) {
+        LoadCostGP ld{*cs, k0, mm, normMode, gs.G, {}};
+        if ((rc = dual_box_march(s, n, H, W, r, 0, ld, sab))) return rc;
+    } else {
+        LoadPlanarGP ld{sc.F0, N, W, gs.G};
+        if ((rc = dual_box_march(s, n, H, W, r, 0, ld, sab))) return rc;
+    }
+    // (a, b) -> means -> a_bar*G + b_bar -> F0; SKWGIF: steer-weighted means boxsum(w*a)/boxsum(w)
+    // over the clipped r2 window (gifs.cpp:587-611)
+    LoadAB lab{sc.F1, sc.F2, N, W, skw ? gs.w : nullptr};
+    StoreOut so{sc.F0, N, W, gs.G, 1.0 / ((double)r * r), skw ? gs.wsum : nullptr, beta};
+    if ((rc = dual_box_march(s, n, H, W, skw ? gs.r2 : r, skw ? 1 : 0, lab, so))) return rc;
     return MDISP_OK;
 }
 
@@ -720,12 +996,8 @@ extern "C" int mdisp_guided_filter(mdisp_ctx* c, const mdisp_image* guide, const
         minmax_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm);
         normalize_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm, NORM_FLOAT, sc.F0);
     }
-    if ((rc = gif_filter_batch(c, gs, sc, 1))) return rc;
-    OutArgs oa;
-    oa.abar = sc.F1; oa.bbar = sc.F2; oa.G = gs.G; oa.N = N; oa.n = 1; oa.filtered = dOut; oa.beta = beta ? dBeta : nullptr;
-    oa.best = nullptr; oa.disp32 = nullptr; oa.disp64 = nullptr; oa.d0 = 0; oa.first = 1;
-    out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
-    MD_HIP(hipGetLastError());
+    if ((rc = gif_filter_batch(c, gs, sc, 1, nullptr, 0, nullptr, NORM_FLOAT, beta ? dBeta : nullptr))) return rc;
+    dOut = sc.F0;
     MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, dOut, (size_t)W * 4, (size_t)W * 4, H));
     if (beta) MD_TRY(md_d2h_2d(c, beta->data, beta->step_bytes, dBeta, (size_t)W * 4, (size_t)W * 4, H));
     MD_HIP(hipStreamSynchronize(s));
@@ -772,12 +1044,15 @@ int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, 
             minmax_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2);
             normalize_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2, NORM_FLOAT, sc.F0);
         } else {
-            cost_minmax_kernel<<<g, 256, 0, s>>>(cs, k0, sc.mm + 2);
-            cost_normalize_kernel<<<g, 256, 0, s>>>(cs, k0, sc.mm + 2, normMode, sc.F0);
+            // per-workgroup partials go through the (otherwise idle) double scratch
+            const dim3 gm((W + 255) / 256, (H + MM_ROWS - 1) / MM_ROWS);
+            u32* part = reinterpret_cast<u32*>(sc.T);
+            cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part);
+            cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
         }
-        if ((rc = gif_filter_batch(c, gs, sc, nb))) return rc;
+        if ((rc = gif_filter_batch(c, gs, sc, nb, hostCosts ? nullptr : &cs, k0, sc.mm + 2, normMode, nullptr))) return rc;
         OutArgs oa;
-        oa.abar = sc.F1; oa.bbar = sc.F2; oa.G = gs.G; oa.N = N; oa.n = nb; oa.filtered = nullptr; oa.beta = nullptr;
+        oa.v = sc.F0; oa.abar = nullptr; oa.bbar = nullptr; oa.G = gs.G; oa.N = N; oa.n = nb; oa.filtered = nullptr; oa.beta = nullptr;
         oa.best = best; oa.disp32 = dDisp32; oa.disp64 = dDisp64; oa.d0 = minD + k0; oa.first = k0 == 0;
         out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
         MD_HIP(hipGetLastError());

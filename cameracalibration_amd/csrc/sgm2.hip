@@ -59,9 +59,7 @@ __device__ __forceinline__ u32 row_min16(u32 v)
 
 constexpr int NR = 8;          // packed registers per lane (16 disparities)
 constexpr int DPL = 16;        // disparities per lane
-constexpr int LPC = 16;        // lanes per pixel  -> up to 256 disparities
 constexpr int CW = 16;         // strip width in columns
-constexpr int RB = 16;         // rows per block (horizontal scan batch)
 
 struct Sgm2Args {
     const u8* cL; size_t pL, strideL;     // census of the left image      [B][H][pL]
