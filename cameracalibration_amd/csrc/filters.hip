@@ -451,23 +451,32 @@ __global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, L
     double ring[TAPS][4];               // [slot][quantity*2 + column]
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
     const int nin = (y1 - y0) + TAPS - 1;
+    // the next input row is requested while the current one is summed
+    typename Load::Raw pre[NLD];
+    auto request_row = [&](int j) {
+        const int ys = r101(y0 - A + j, H);
+#pragma unroll
+        for (int e = 0; e < NLD; e++)
+            if (lane + 64 * e < ROWW) pre[e] = ld.fetch(xsrc[e], ys, k);
+    };
+    request_row(0);
     for (int j0 = 0; j0 < nin; j0 += TAPS) {
 #pragma unroll
         for (int u = 0; u < TAPS; u++) {
             const int j = j0 + u;
             if (j < nin) {
-                const int ys = r101(y0 - A + j, H);
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < NLD; e++) {
                     const int i = lane + 64 * e;
                     if (i < ROWW) {
                         float q0, q1;
-                        ld(xsrc[e], ys, k, q0, q1);
+                        ld.finish(pre[e], q0, q1);
                         row0[i] = q0; row1[i] = q1;
                     }
                 }
                 __syncthreads();
+                if (j + 1 < nin) request_row(j + 1);
                 double h[4];
                 {
                     double a0 = 0.0, a1 = 0.0;
@@ -501,39 +510,60 @@ __device__ __forceinline__ NormScale norm_scale(u32 olo, u32 ohi)
     return n;
 }
 
+// Load functors: fetch() only issues the memory reads of one element (so that the next row can be
+// requested before the current one is consumed), finish() turns them into the two filter inputs.
 // P = normalised integer cost computed on the fly; (P, G*P)
 struct LoadCostGP {
     CostSrc c; int k0; const u32* mm; int mode; const float* G;
     NormScale ns;
+    struct Raw { int r, p; float g; };
     __device__ void begin(int k) { ns = norm_scale(mm[2 * k], mm[2 * k + 1]); }
-    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    __device__ Raw fetch(int x, int y, int k) const
     {
-        const float v = (float)raw_cost(c, x, y, k0 + k);
-        const float P = mode == NORM_DOUBLE ? (float)((double)v * ns.dscale + ns.dshift) : __fadd_rn(__fmul_rn(v, ns.scale), ns.shift);
-        q0 = P; q1 = __fmul_rn(P, G[(size_t)y * c.W + x]);
+        Raw w;
+        w.r = c.ref[(size_t)y * c.rp + x]; w.p = c.pad[(size_t)y * c.pp + x + c.off0 + (k0 + k) * c.offStep];
+        w.g = G[(size_t)y * c.W + x];
+        return w;
     }
+    __device__ void finish(const Raw& w, float& q0, float& q1) const
+    {
+        const float v = (float)(c.kind == MD_COST_HAMMING ? __popc((u32)(w.r ^ w.p)) : abs(w.r - w.p));
+        const float P = mode == NORM_DOUBLE ? (float)((double)v * ns.dscale + ns.dshift) : __fadd_rn(__fmul_rn(v, ns.scale), ns.shift);
+        q0 = P; q1 = __fmul_rn(P, w.g);
+    }
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const { finish(fetch(x, y, k), q0, q1); }
 };
 // P = already normalised planar slices; (P, G*P)
 struct LoadPlanarGP {
     const float* P; size_t N; int W; const float* G;
+    struct Raw { float p, g; };
     __device__ void begin(int) {}
-    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    __device__ Raw fetch(int x, int y, int k) const
     {
         const size_t i = (size_t)y * W + x;
-        const float p = P[(size_t)k * N + i];
-        q0 = p; q1 = __fmul_rn(p, G[i]);
+        Raw w; w.p = P[(size_t)k * N + i]; w.g = G[i];
+        return w;
     }
+    __device__ void finish(const Raw& w, float& q0, float& q1) const { q0 = w.p; q1 = __fmul_rn(w.p, w.g); }
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const { finish(fetch(x, y, k), q0, q1); }
 };
 // (a, b), optionally both times the steer weight
 struct LoadAB {
     const float* A; const float* B; size_t N; int W; const float* w;
+    struct Raw { float a, b, ww; };
     __device__ void begin(int) {}
-    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const
+    __device__ Raw fetch(int x, int y, int k) const
     {
         const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
-        q0 = A[o]; q1 = B[o];
-        if (w) { const float ww = w[i]; q0 = __fmul_rn(q0, ww); q1 = __fmul_rn(q1, ww); }
+        Raw r; r.a = A[o]; r.b = B[o]; r.ww = w ? w[i] : 1.0f;
+        return r;
     }
+    __device__ void finish(const Raw& r, float& q0, float& q1) const
+    {
+        q0 = r.a; q1 = r.b;
+        if (w) { q0 = __fmul_rn(q0, r.ww); q1 = __fmul_rn(q1, r.ww); }
+    }
+    __device__ void operator()(int x, int y, int k, float& q0, float& q1) const { finish(fetch(x, y, k), q0, q1); }
 };
 // means of P and G*P -> a = (corrGP - meanG*meanP) / den, b = meanP - a*meanG   (gifs.cpp:96,127-128)
 struct StoreAB {
