@@ -451,15 +451,16 @@ __global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, L
     double ring[TAPS][4];               // [slot][quantity*2 + column]
     double cs[4] = {0.0, 0.0, 0.0, 0.0};
     const int nin = (y1 - y0) + TAPS - 1;
-    // the next input row is requested while the current one is summed
-    typename Load::Raw pre[NLD];
-    auto request_row = [&](int j) {
+    // input rows are requested two rows ahead of the one being summed
+    typename Load::Raw preA[NLD], preB[NLD];
+    auto request_row = [&](int j, typename Load::Raw (&pre)[NLD]) {
         const int ys = r101(y0 - A + j, H);
 #pragma unroll
         for (int e = 0; e < NLD; e++)
             if (lane + 64 * e < ROWW) pre[e] = ld.fetch(xsrc[e], ys, k);
     };
-    request_row(0);
+    request_row(0, preA);
+    if (nin > 1) request_row(1, preB);
     for (int j0 = 0; j0 < nin; j0 += TAPS) {
 #pragma unroll
         for (int u = 0; u < TAPS; u++) {
@@ -471,12 +472,14 @@ __global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, L
                     const int i = lane + 64 * e;
                     if (i < ROWW) {
                         float q0, q1;
-                        ld.finish(pre[e], q0, q1);
+                        ld.finish(preA[e], q0, q1);
                         row0[i] = q0; row1[i] = q1;
                     }
                 }
                 __syncthreads();
-                if (j + 1 < nin) request_row(j + 1);
+#pragma unroll
+                for (int e = 0; e < NLD; e++) preA[e] = preB[e];
+                if (j + 2 < nin) request_row(j + 2, preB);
                 double h[4];
                 {
                     double a0 = 0.0, a1 = 0.0;
