@@ -387,34 +387,75 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
     const int H = g.H, W = g.W;
     const int a = g.ksz / 2;
     const int taps = g.mode == 0 ? g.ksz : 2 * a;
-    const int rowW = MW + taps - 1, rowPad = (rowW + 3) & ~3;
+    const int rowW = MW + taps - 1;                       // <= 2 * MW: two elements per thread
+    // LDS: the input row of both quantities (float), their running prefix sums (double, one
+    // leading zero), the ring of window sums
     float* row0 = reinterpret_cast<float*>(march_smem);
-    float* row1 = row0 + rowPad;
-    RingT* ring0 = reinterpret_cast<RingT*>(row1 + rowPad + (rowPad & 1 ? 1 : 0));
+    float* row1 = row0 + 2 * MW;
+    double* pre0 = reinterpret_cast<double*>(row1 + 2 * MW);
+    double* pre1 = pre0 + 2 * MW + 2;
+    RingT* ring0 = reinterpret_cast<RingT*>(pre1 + 2 * MW + 2);
     RingT* ring1 = ring0 + (size_t)taps * MW;
+    __shared__ double wtot[2][2];
     const int x0 = blockIdx.x * MW, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
-    const int tx = threadIdx.x, x = x0 + tx;
+    const int tx = threadIdx.x, x = x0 + tx, wave = tx >> 6, lane = tx & 63;
     ld.begin(k);
+    // the two row elements this thread loads: tx and tx + MW; source column and validity fixed per thread
+    int xsrc[2]; bool xok[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int i = tx + MW * e, xs = x0 - a + i;
+        xok[e] = i < rowW && (g.mode == 0 || (xs >= 0 && xs < W - 1));
+        xsrc[e] = g.mode == 0 ? r101(xs, W) : min(max(xs, 0), W - 1);
+    }
+    typename Load::Raw raw[2];
+    auto row_source = [&](int j, int& ys) -> bool {
+        const int yy = y0 - a + j;
+        if (g.mode == 0) { ys = r101(yy, H); return true; }
+        ys = min(max(yy, 0), H - 1);
+        return yy >= 0 && yy < H - 1;
+    };
+    auto request_row = [&](int j) {
+        int ys;
+        if (!row_source(j, ys)) return;
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (xok[e]) raw[e] = ld.fetch(xsrc[e], ys, k);
+    };
     double c0 = 0.0, c1 = 0.0;
     const int nin = (y1 - y0) + taps - 1;
+    request_row(0);
     for (int j = 0; j < nin; j++) {
-        const int yy = y0 - a + j;
-        int ys = yy; bool rowValid = true;
-        if (g.mode == 0) ys = r101(yy, H); else rowValid = yy >= 0 && yy < H - 1;
-        __syncthreads();                       // the previous row's window sums are done with row0/row1
-        if (rowValid) {
-            for (int i = tx; i < rowW; i += MW) {
-                int xs = x0 - a + i; float q0 = 0.f, q1 = 0.f;
-                if (g.mode == 0) { xs = r101(xs, W); ld(xs, ys, k, q0, q1); }
-                else if (xs >= 0 && xs < W - 1) ld(xs, ys, k, q0, q1);
-                row0[i] = q0; row1[i] = q1;
-            }
+        int ysd;
+        const bool rowValid = row_source(j, ysd);
+        __syncthreads();                       // the previous row's sums are done with the row buffers
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float q0 = 0.f, q1 = 0.f;
+            if (rowValid && xok[e]) ld.finish(raw[e], q0, q1);
+            row0[tx + MW * e] = q0; row1[tx + MW * e] = q1;
         }
         __syncthreads();
-        double h0 = 0.0, h1 = 0.0;
-        if (rowValid) {
-            for (int i = 0; i < taps; i++) { h0 += (double)row0[tx + i]; h1 += (double)row1[tx + i]; }
+        if (j + 1 < nin) request_row(j + 1);
+        // horizontal window sums through an exact (double) prefix sum of the row: thread t owns
+        // elements 2t and 2t+1
+        const float2 e0 = *reinterpret_cast<const float2*>(&row0[2 * tx]);
+        const float2 e1 = *reinterpret_cast<const float2*>(&row1[2 * tx]);
+        double s0 = (double)e0.x + (double)e0.y, s1 = (double)e1.x + (double)e1.y;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
+            if (lane >= d) { s0 += u0; s1 += u1; }
         }
+        if (lane == 63) { wtot[wave][0] = s0; wtot[wave][1] = s1; }
+        __syncthreads();
+        if (wave == 1) { s0 += wtot[0][0]; s1 += wtot[0][1]; }
+        // s = inclusive sum through element 2t+1; pre[i] = sum of elements [0, i)
+        pre0[2 * tx + 2] = s0; pre0[2 * tx + 1] = s0 - (double)e0.y;
+        pre1[2 * tx + 2] = s1; pre1[2 * tx + 1] = s1 - (double)e1.y;
+        if (tx == 0) { pre0[0] = 0.0; pre1[0] = 0.0; }
+        __syncthreads();
+        const double h0 = pre0[tx + taps] - pre0[tx], h1 = pre1[tx + taps] - pre1[tx];
         const RingT r0 = (RingT)h0, r1 = (RingT)h1;
         const int slot = j % taps;
         ring0[(size_t)slot * MW + tx] = r0; ring1[(size_t)slot * MW + tx] = r1;
@@ -594,7 +635,7 @@ struct StoreOut {
     }
 };
 
-static bool march_supported(int ksz) { return ksz >= 1 && ksz <= 75; }   // ring of 2*ksz*128 doubles within 160 KB of LDS
+static bool march_supported(int ksz) { return ksz >= 1 && ksz <= 71; }   // ring of 2*ksz*128 doubles + row buffers within 160 KB of LDS
 
 template <class Load, class Store>
 static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode, const Load& ld, const Store& st)
@@ -615,16 +656,15 @@ static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode,
         MD_HIP(hipGetLastError());
         return MDISP_OK;
     }
-    const int rowW = MW + taps - 1, rowPad = (rowW + 3) & ~3;
     dim3 grid((W + MW - 1) / MW, (H + g.band - 1) / g.band, n);
     // the ring stays in double so that the window sums of float inputs are exact whatever the order
-    const size_t lds = (size_t)(2 * rowPad + 2) * sizeof(float) + 2 * (size_t)taps * MW * sizeof(double);
+    const size_t lds = (size_t)4 * MW * sizeof(float) + (size_t)2 * (2 * MW + 2) * sizeof(double) + 2 * (size_t)taps * MW * sizeof(double);
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static size_t raised = 0;              // per instantiation; one process drives one device
+        if (lds > raised) {
             MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_box_march_kernel<double, Load, Store>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = lds;
         }
     }
     dual_box_march_kernel<double, Load, Store><<<grid, MW, lds, s>>>(g, ld, st);
@@ -902,7 +942,7 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
     const bool skw = gs.type == MDISP_SKWGIF;
     int rc;
     if (!march_supported(r) || (skw && !march_supported(gs.r2))) {
-        mdisp_set_error("guided-filter window above 75 is not supported");
+        mdisp_set_error("guided-filter window above 71 is not supported");
         return MDISP_E_UNSUPPORTED;
     }
     // (P, G*P) -> means -> a -> F1, b -> F2   (gifs.cpp:60-61,71,96,127-128)

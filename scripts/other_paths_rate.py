@@ -59,3 +59,10 @@ dt, r = host_rate(lambda: api.computeSAD_BFOpti(p), H, W, D)
 print(f"computeSAD_BFOpti  {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
 dt, r = host_rate(lambda: api.computeSAD_inteOpti(p), H, W, D)
 print(f"computeSAD_inteOpti {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
+# the steer-weighted aggregation of the large-pair configuration (winSize 35, r2 15), at 1080p with 64 disparities
+H, W, D = 1080, 1920, 64
+L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=35, minDisparity=0, maxDisparity=D - 1, isDispLeft=True)
+for name, gif in (("GIF", api.GIF), ("SKWGIF", api.SKWGIF)):
+    dt, r = host_rate(lambda: api.asw_gifs(p, 0.01, gif, 15, 0.1, 0.5, api.COST_CENSUS), H, W, D, n=2)
+    print(f"asw_gifs {name:7s} win 35 r2 15 {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
