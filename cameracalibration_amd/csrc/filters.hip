@@ -370,9 +370,9 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 // ---------------------------------------------------------------------------------------------
 // Fused separable box filter of TWO quantities at once, marching down the image: a workgroup owns
 // MW columns of a row band; every input row is loaded once into LDS (with its horizontal halo),
-// each thread forms the horizontal window sums of its column in double, keeps them in an LDS ring
-// of `taps` rows and maintains the vertical running sums in registers (add the newest row, emit,
-// subtract the oldest -- the order of cv::boxFilter's ColumnSum).  The window sums never travel
+// the horizontal window sums come from an exact double prefix sum of the row, and every thread
+// keeps the vertical running sum of its column in registers (add the entering row, subtract the
+// leaving one -- cv::boxFilter's ColumnSum).  The window sums never travel
 // through HBM, and the element-wise stage that follows the filter in the guided filter (a, b from
 // the means; a_bar*G + b_bar from the second pair of means) runs in the store functor.
 // Window: starts at p - ksz/2; mode 0: ksz taps, BORDER_REFLECT_101; mode 1: 2*(ksz/2) taps, zero
@@ -380,23 +380,20 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 #define MW 128
 struct MarchGeom { int H, W, ksz, mode, band; };
 
-template <typename RingT, class Load, class Store>
+template <class Load, class Store>
 __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld, Store st)
 {
-    extern __shared__ unsigned char march_smem[];
+    // LDS: per input step the element-wise difference (entering row - leaving row) of both
+    // quantities and its prefix sums, all in double.  No ring of past rows is kept: the row that
+    // leaves the window is fetched again (its bytes are still in cache), which leaves LDS almost
+    // empty and lets many workgroups share a CU -- this loop is latency-bound, not bandwidth-bound.
+    __shared__ double dd0[2 * MW], dd1[2 * MW];
+    __shared__ double pre0[2 * MW + 2], pre1[2 * MW + 2];
+    __shared__ double wtot[2][2];
     const int H = g.H, W = g.W;
     const int a = g.ksz / 2;
     const int taps = g.mode == 0 ? g.ksz : 2 * a;
     const int rowW = MW + taps - 1;                       // <= 2 * MW: two elements per thread
-    // LDS: the input row of both quantities (float), their running prefix sums (double, one
-    // leading zero), the ring of window sums
-    float* row0 = reinterpret_cast<float*>(march_smem);
-    float* row1 = row0 + 2 * MW;
-    double* pre0 = reinterpret_cast<double*>(row1 + 2 * MW);
-    double* pre1 = pre0 + 2 * MW + 2;
-    RingT* ring0 = reinterpret_cast<RingT*>(pre1 + 2 * MW + 2);
-    RingT* ring1 = ring0 + (size_t)taps * MW;
-    __shared__ double wtot[2][2];
     const int x0 = blockIdx.x * MW, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
     const int tx = threadIdx.x, x = x0 + tx, wave = tx >> 6, lane = tx & 63;
     ld.begin(k);
@@ -408,40 +405,48 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
         xok[e] = i < rowW && (g.mode == 0 || (xs >= 0 && xs < W - 1));
         xsrc[e] = g.mode == 0 ? r101(xs, W) : min(max(xs, 0), W - 1);
     }
-    typename Load::Raw raw[2];
-    auto row_source = [&](int j, int& ys) -> bool {
+    auto row_source = [&](int j, int& ys) -> bool {       // input step j -> source row, false if it contributes zeros
         const int yy = y0 - a + j;
         if (g.mode == 0) { ys = r101(yy, H); return true; }
         ys = min(max(yy, 0), H - 1);
         return yy >= 0 && yy < H - 1;
     };
-    auto request_row = [&](int j) {
+    typename Load::Raw rawNew[2], rawOld[2];
+    auto request = [&](int j, typename Load::Raw (&raw)[2]) {
         int ys;
-        if (!row_source(j, ys)) return;
+        if (j < 0 || !row_source(j, ys)) return;
 #pragma unroll
         for (int e = 0; e < 2; e++)
             if (xok[e]) raw[e] = ld.fetch(xsrc[e], ys, k);
     };
+    auto value = [&](int j, const typename Load::Raw (&raw)[2], int e, double& v0, double& v1) {
+        int ys;
+        v0 = 0.0; v1 = 0.0;
+        if (j >= 0 && xok[e] && row_source(j, ys)) {
+            float q0, q1;
+            ld.finish(raw[e], q0, q1);
+            v0 = (double)q0; v1 = (double)q1;
+        }
+    };
     double c0 = 0.0, c1 = 0.0;
     const int nin = (y1 - y0) + taps - 1;
-    request_row(0);
+    request(0, rawNew);
+    request(-taps, rawOld);
     for (int j = 0; j < nin; j++) {
-        int ysd;
-        const bool rowValid = row_source(j, ysd);
-        __syncthreads();                       // the previous row's sums are done with the row buffers
+        __syncthreads();                       // the previous step is done with the LDS buffers
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            float q0 = 0.f, q1 = 0.f;
-            if (rowValid && xok[e]) ld.finish(raw[e], q0, q1);
-            row0[tx + MW * e] = q0; row1[tx + MW * e] = q1;
+            double n0, n1, o0, o1;
+            value(j, rawNew, e, n0, n1);
+            value(j - taps, rawOld, e, o0, o1);
+            dd0[tx + MW * e] = n0 - o0; dd1[tx + MW * e] = n1 - o1;
         }
         __syncthreads();
-        if (j + 1 < nin) request_row(j + 1);
-        // horizontal window sums through an exact (double) prefix sum of the row: thread t owns
-        // elements 2t and 2t+1
-        const float2 e0 = *reinterpret_cast<const float2*>(&row0[2 * tx]);
-        const float2 e1 = *reinterpret_cast<const float2*>(&row1[2 * tx]);
-        double s0 = (double)e0.x + (double)e0.y, s1 = (double)e1.x + (double)e1.y;
+        if (j + 1 < nin) { request(j + 1, rawNew); request(j + 1 - taps, rawOld); }
+        // exact prefix sum of the difference row: thread t owns elements 2t and 2t+1
+        const double2 e0 = *reinterpret_cast<const double2*>(&dd0[2 * tx]);
+        const double2 e1 = *reinterpret_cast<const double2*>(&dd1[2 * tx]);
+        double s0 = e0.x + e0.y, s1 = e1.x + e1.y;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const double u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
@@ -451,20 +456,15 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
         __syncthreads();
         if (wave == 1) { s0 += wtot[0][0]; s1 += wtot[0][1]; }
         // s = inclusive sum through element 2t+1; pre[i] = sum of elements [0, i)
-        pre0[2 * tx + 2] = s0; pre0[2 * tx + 1] = s0 - (double)e0.y;
-        pre1[2 * tx + 2] = s1; pre1[2 * tx + 1] = s1 - (double)e1.y;
+        pre0[2 * tx + 2] = s0; pre0[2 * tx + 1] = s0 - e0.y;
+        pre1[2 * tx + 2] = s1; pre1[2 * tx + 1] = s1 - e1.y;
         if (tx == 0) { pre0[0] = 0.0; pre1[0] = 0.0; }
         __syncthreads();
-        const double h0 = pre0[tx + taps] - pre0[tx], h1 = pre1[tx + taps] - pre1[tx];
-        const RingT r0 = (RingT)h0, r1 = (RingT)h1;
-        const int slot = j % taps;
-        ring0[(size_t)slot * MW + tx] = r0; ring1[(size_t)slot * MW + tx] = r1;
-        c0 += (double)r0; c1 += (double)r1;
+        // the window sums change by (entering row's window sum) - (leaving row's window sum)
+        c0 += pre0[tx + taps] - pre0[tx]; c1 += pre1[tx + taps] - pre1[tx];
         if (j >= taps - 1) {
             const int y = y0 + j - (taps - 1);
             if (x < W) st(x, y, k, c0, c1);
-            const int os = (j + 1) % taps;     // the oldest row of the window just emitted
-            c0 -= (double)ring0[(size_t)os * MW + tx]; c1 -= (double)ring1[(size_t)os * MW + tx];
         }
     }
 }
@@ -635,7 +635,7 @@ struct StoreOut {
     }
 };
 
-static bool march_supported(int ksz) { return ksz >= 1 && ksz <= 71; }   // ring of 2*ksz*128 doubles + row buffers within 160 KB of LDS
+static bool march_supported(int ksz) { return ksz >= 1 && ksz <= MW; }    // a row and its halo are two elements per thread
 
 template <class Load, class Store>
 static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode, const Load& ld, const Store& st)
@@ -657,17 +657,7 @@ static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode,
         return MDISP_OK;
     }
     dim3 grid((W + MW - 1) / MW, (H + g.band - 1) / g.band, n);
-    // the ring stays in double so that the window sums of float inputs are exact whatever the order
-    const size_t lds = (size_t)4 * MW * sizeof(float) + (size_t)2 * (2 * MW + 2) * sizeof(double) + 2 * (size_t)taps * MW * sizeof(double);
-    if (lds > 64 * 1024) {
-        static size_t raised = 0;              // per instantiation; one process drives one device
-        if (lds > raised) {
-            MD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dual_box_march_kernel<double, Load, Store>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised = lds;
-        }
-    }
-    dual_box_march_kernel<double, Load, Store><<<grid, MW, lds, s>>>(g, ld, st);
+    dual_box_march_kernel<Load, Store><<<grid, MW, 0, s>>>(g, ld, st);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }
@@ -942,7 +932,7 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
     const bool skw = gs.type == MDISP_SKWGIF;
     int rc;
     if (!march_supported(r) || (skw && !march_supported(gs.r2))) {
-        mdisp_set_error("guided-filter window above 71 is not supported");
+        mdisp_set_error("guided-filter window above %d is not supported", MW);
         return MDISP_E_UNSUPPORTED;
     }
     // (P, G*P) -> means -> a -> F1, b -> F2   (gifs.cpp:60-61,71,96,127-128)
