@@ -303,7 +303,10 @@ static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     size_t o_cr = cv.take(b->pitchP * H), o_cp = cv.take(b->pitchP * H), o_scr = cv.take(b->pitchP * H);
     size_t o_st = cv.take(b->pitch3 * H), o_out = cv.take(out_bytes);
     size_t o_I = 0, o_best = 0;
-    if (need_sat) { o_I = cv.take((size_t)(H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 4); }
+    if (need_sat) {
+        const int nt = md_sad_inte_tables(H, W, p->maxDisparity - p->minDisparity + 1);
+        o_I = cv.take((size_t)nt * (H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 4);
+    }
     size_t o_extra = cv.take(extra_bytes);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;

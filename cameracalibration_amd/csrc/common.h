@@ -99,7 +99,8 @@ int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL,
 // stereo.hip
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                     int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op);
-// I: (H+1)*(W+1) ints, best: H*W ints of device scratch
+// I: md_sad_inte_tables() tables of (H+1)*(W+1) ints, best: H*W ints of device scratch
+int md_sad_inte_tables(int H, int W, int D);
 int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                 int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best);
 int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, float thresh, u8* vL, u8* vR);

@@ -170,16 +170,21 @@ int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size
 // (getMatVal, :159-171) -- so the window is 2h x 2h and the last h columns/rows produce the
 // reference's negative "garbage" costs, reproduced here exactly.
 
+// Slices are processed in batches of `nb` tables (grid z / y = slice) so that the serial column
+// scan of one slice overlaps with those of the others.
+
 // exclusive row prefix of |ref - pad(x+off)|: P[y][x] = sum_{x' < x} diff, x in [0, W]
 __global__ __launch_bounds__(256) void sad_row_prefix_kernel(const u8* __restrict__ ref, size_t rp, const u8* __restrict__ pad,
-                                                             size_t pp, int W, int off, int* __restrict__ P, int PW)
+                                                             size_t pp, int W, int off0, int offStep, int* __restrict__ Pbase,
+                                                             int PW, size_t tableStride)
 {
     __shared__ int part[256];
-    const int y = blockIdx.x, tid = threadIdx.x;
+    const int y = blockIdx.x, tid = threadIdx.x, k = blockIdx.y;
     const int chunk = (W + 255) / 256;
     const int xb = tid * chunk, xe = min(W, xb + chunk);
     const u8* r = ref + (size_t)y * rp;
-    const u8* p = pad + (size_t)y * pp + off;
+    const u8* p = pad + (size_t)y * pp + off0 + k * offStep;
+    int* P = Pbase + (size_t)k * tableStride;
     int s = 0;
     for (int x = xb; x < xe; x++) { int a = r[x], b = p[x]; s += a > b ? a - b : b - a; }
     part[tid] = s;
@@ -202,10 +207,11 @@ __global__ __launch_bounds__(256) void sad_row_prefix_kernel(const u8* __restric
 }
 
 // in-place column prefix: I[y+1][x] = sum_{y' <= y} P[y'][x]; row 0 of I is zero.  I has H+1 rows.
-__global__ __launch_bounds__(256) void sad_col_prefix_kernel(int* __restrict__ I, int H, int PW)
+__global__ __launch_bounds__(64) void sad_col_prefix_kernel(int* __restrict__ Ibase, int H, int PW, size_t tableStride)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= PW) return;
+    int* I = Ibase + (size_t)blockIdx.y * tableStride;
     int run = 0;
     // rows are stored shifted by one: input row y lives at I[(y+1)*PW]
     for (int y = 1; y <= H; y++) {
@@ -215,30 +221,55 @@ __global__ __launch_bounds__(256) void sad_col_prefix_kernel(int* __restrict__ I
     I[x] = 0;
 }
 
-__global__ __launch_bounds__(256) void sad_inte_wta_kernel(const int* __restrict__ I, int H, int W, int PW, int h, int k, int d,
-                                                           int* __restrict__ best, u8* __restrict__ out, size_t op)
+// four-corner lookups of the nb tables of a batch against the running best (strict '<': the lowest
+// disparity wins ties, methods_disp.cpp:246-262)
+__global__ __launch_bounds__(256) void sad_inte_wta_kernel(const int* __restrict__ Ibase, size_t tableStride, int nb, int H, int W,
+                                                           int PW, int h, int first, int d0, int* __restrict__ best,
+                                                           u8* __restrict__ out, size_t op)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
-    auto get = [&](int xx, int yy) -> int {
-        return (xx >= 0 && xx <= W && yy >= 0 && yy <= H) ? I[(size_t)yy * PW + xx] : 0;
-    };
-    const int c = get(x + h, y + h) - get(x + h, y - h) - get(x - h, y + h) + get(x - h, y - h);
+    const bool xh = x + h <= W, xl = x - h >= 0, yh = y + h <= H, yl = y - h >= 0;   // a corner outside the table reads 0
     const size_t i = (size_t)y * W + x;
-    if (k == 0 || c < best[i]) { best[i] = c; out[(size_t)y * op + x] = (u8)(d & 0xFF); }
+    int b = first ? 0 : best[i];
+    int bd = first ? 0 : out[(size_t)y * op + x];
+    bool have = !first;
+    for (int k = 0; k < nb; k++) {
+        const int* I = Ibase + (size_t)k * tableStride;
+        int c = 0;
+        if (xh && yh) c += I[(size_t)(y + h) * PW + x + h];
+        if (xh && yl) c -= I[(size_t)(y - h) * PW + x + h];
+        if (xl && yh) c -= I[(size_t)(y + h) * PW + x - h];
+        if (xl && yl) c += I[(size_t)(y - h) * PW + x - h];
+        if (!have || c < b) { b = c; bd = (d0 + k) & 0xFF; have = true; }
+    }
+    best[i] = b; out[(size_t)y * op + x] = (u8)bd;
 }
 
+// number of integral tables processed per batch: as many as fit half a gigabyte
+int md_sad_inte_tables(int H, int W, int D)
+{
+    const size_t one = (size_t)(H + 1) * (W + 1) * sizeof(int);
+    size_t n = ((size_t)512 << 20) / one;
+    if (n < 1) n = 1;
+    if (n > (size_t)D) n = D;
+    return (int)n;
+}
+
+// I: md_sad_inte_tables() tables of (H+1)*(W+1) ints, best: H*W ints of device scratch
 int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                 int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best)
 {
     MD_REQUIRE((double)H * W * 255.0 < 2147483647.0, MDISP_E_RANGE, "integral table overflows 32 bits for %dx%d", W, H);
     const int PW = W + 1, D = maxD - minD + 1;
-    for (int k = 0; k < D; k++) {
-        const int off = off0 + k * offStep;
-        sad_row_prefix_kernel<<<H, 256, 0, s>>>(ref, rp, pad, pp, W, off, I + PW, PW);
-        sad_col_prefix_kernel<<<(PW + 255) / 256, 256, 0, s>>>(I, H, PW);
+    const int n = md_sad_inte_tables(H, W, D);
+    const size_t stride = (size_t)(H + 1) * PW;
+    for (int k0 = 0; k0 < D; k0 += n) {
+        const int nb = D - k0 < n ? D - k0 : n;
+        sad_row_prefix_kernel<<<dim3(H, nb), 256, 0, s>>>(ref, rp, pad, pp, W, off0 + k0 * offStep, offStep, I + PW, PW, stride);
+        sad_col_prefix_kernel<<<dim3((PW + 63) / 64, nb), 64, 0, s>>>(I, H, PW, stride);
         dim3 grid((W + 255) / 256, H);
-        sad_inte_wta_kernel<<<grid, 256, 0, s>>>(I, H, W, PW, win / 2, k, minD + k, best, out, op);
+        sad_inte_wta_kernel<<<grid, 256, 0, s>>>(I, stride, nb, H, W, PW, win / 2, k0 == 0, minD + k0, best, out, op);
     }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
