@@ -120,6 +120,11 @@ def countCensusImg_multiScale(src, scale, ctx=None):
     return _census(src, MULTISCALE_CENSUS, scale, ctx)
 
 
+def countCensusImg_multiScale2(src, scale, ctx=None):
+    """methods_disp.h:56: multi-scale census remapped to the rank of its code in the image's histogram."""
+    return _census(src, STATISTIC_MULTISCALE_CENSUS, scale, ctx)
+
+
 def countHummingDist(src1, src2, ctx=None):
     a, b = _u8(src1), _u8(src2)
     dst = np.empty(a.shape, dtype=np.int32)

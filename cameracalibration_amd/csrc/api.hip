@@ -236,7 +236,7 @@ extern "C" int mdisp_census_transform(mdisp_ctx* c, const mdisp_image* src, int 
     const int H = src->rows, W = src->cols;
     const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
     Carver cv;
-    size_t o_src = cv.take(pitch * H), o_dst = cv.take(pitch * H), o_scr = cv.take(pitch * H), o_stage = cv.take(p3 * H);
+    size_t o_src = cv.take(pitch * H), o_dst = cv.take(pitch * H), o_scr = cv.take(pitch * H + MD_CENSUS_SCRATCH_TAIL), o_stage = cv.take(p3 * H);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     if ((rc = upload_gray(c, src, base + o_src, pitch, base + o_stage, p3))) return rc;
@@ -300,7 +300,7 @@ static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     b->pitchW = md_align(W, 256); b->pitchP = md_align(Wp, 256); b->pitch3 = md_align((size_t)W * 3, 256);
     Carver cv;
     size_t o_ref = cv.take(b->pitchW * H), o_oth = cv.take(b->pitchW * H), o_pad = cv.take(b->pitchP * H);
-    size_t o_cr = cv.take(b->pitchP * H), o_cp = cv.take(b->pitchP * H), o_scr = cv.take(b->pitchP * H);
+    size_t o_cr = cv.take(b->pitchP * H), o_cp = cv.take(b->pitchP * H), o_scr = cv.take(b->pitchP * H + MD_CENSUS_SCRATCH_TAIL);
     size_t o_st = cv.take(b->pitch3 * H), o_out = cv.take(out_bytes);
     size_t o_I = 0, o_best = 0;
     if (need_sat) {
@@ -385,7 +385,7 @@ extern "C" int mdisp_census_stereo_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     const int Wp = cols + p->maxDisparity;
     const size_t pitchP = md_align(Wp, 256);
     Carver cv;
-    size_t o_pad = cv.take(pitchP * rows), o_cr = cv.take(pitchP * rows), o_cp = cv.take(pitchP * rows), o_scr = cv.take(pitchP * rows);
+    size_t o_pad = cv.take(pitchP * rows), o_cr = cv.take(pitchP * rows), o_cp = cv.take(pitchP * rows), o_scr = cv.take(pitchP * rows + MD_CENSUS_SCRATCH_TAIL);
     size_t o_gif = cv.take(agg_mode == MDISP_AGG_GUIDED ? md_gif_scratch_bytes(rows, cols, p->maxDisparity - p->minDisparity + 1) : 0);
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;

@@ -221,6 +221,46 @@ static int launch_census3x3(hipStream_t s, const u8* src, size_t sp, int H, int 
 }
 
 // src and dst rows must be padded to a multiple of 4 bytes (pitch % 4 == 0, pitch >= roundup4(W)).
+// ---- STATISTIC_MULTISCALE_CENSUS (countCensusImg_multiScale2, methods_disp.cpp:677-714) ----
+// histogram of the multi-scale codes (calcHist with 256 bins over [0,255): code 255 is dropped),
+// rank table, remap.  All on the device, no host round trip.
+__global__ __launch_bounds__(256) void code_hist_kernel(const u8* __restrict__ img, size_t pitch, int H, int W, u32* __restrict__ hist)
+{
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int y = blockIdx.y; y < H; y += gridDim.y)
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
+            const int v = img[(size_t)y * pitch + x];
+            if (v < 255) atomicAdd(&h[v], 1u);
+        }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// The reference sorts the counts in decreasing order and, for i = 0..62, gives every bin whose
+// count equals the i-th sorted count the code i (later i overwrite earlier ones); all other bins
+// get 64.  With g = number of bins with a larger count and e = number with an equal count, the
+// sorted positions holding this bin's count are g .. g+e-1, so the code is min(g+e-1, 62) when
+// g <= 62, else 64.
+__global__ __launch_bounds__(256) void rank_table_kernel(const u32* __restrict__ hist, u8* __restrict__ table)
+{
+    __shared__ u32 h[256];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    const u32 mine = h[threadIdx.x];
+    int g = 0, e = 0;
+    for (int j = 0; j < 256; j++) { g += h[j] > mine; e += h[j] == mine; }
+    table[threadIdx.x] = (u8)(g <= 62 ? min(g + e - 1, 62) : 64);
+}
+__global__ __launch_bounds__(256) void apply_table_kernel(u8* __restrict__ img, size_t pitch, int H, int W, const u8* __restrict__ table)
+{
+    __shared__ u8 t[256];
+    t[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < W) img[(size_t)y * pitch + x] = t[img[(size_t)y * pitch + x]];
+}
+
 int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int method, int arg, u8* dst, size_t dpitch,
               u8* scratch)
 {
@@ -259,9 +299,23 @@ int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int met
         MD_HIP(hipGetLastError());
         return MDISP_OK;
     }
-    case MDISP_STATISTIC_MULTISCALE_CENSUS:
-        mdisp_set_error("STATISTIC_MULTISCALE_CENSUS (histogram rank remap) is not built yet");
-        return MDISP_E_UNSUPPORTED;
+    case MDISP_STATISTIC_MULTISCALE_CENSUS: {
+        MD_REQUIRE(scratch, MDISP_E_BADARG, "multi-scale census needs a scratch image");
+        dim3 grid((W + 255) / 256, H);
+        cell_mean_kernel<<<grid, 256, 0, s>>>(src, spitch, H, W, arg / 3, scratch, dpitch);
+        MD_HIP(hipGetLastError());
+        int rc = launch_census3x3(s, scratch, dpitch, H, W, dst, dpitch, nullptr);
+        if (rc) return rc;
+        // histogram and table live behind the scratch image (MD_CENSUS_SCRATCH_TAIL bytes)
+        u32* hist = reinterpret_cast<u32*>(scratch + md_align((size_t)H * dpitch, 256));
+        u8* table = reinterpret_cast<u8*>(hist + 256);
+        MD_HIP(hipMemsetAsync(hist, 0, 256 * sizeof(u32), s));
+        code_hist_kernel<<<dim3(4, 64), 256, 0, s>>>(dst, dpitch, H, W, hist);
+        rank_table_kernel<<<1, 256, 0, s>>>(hist, table);
+        apply_table_kernel<<<grid, 256, 0, s>>>(dst, dpitch, H, W, table);
+        MD_HIP(hipGetLastError());
+        return MDISP_OK;
+    }
     case MDISP_CENSUS_2017:
         mdisp_set_error("CENSUS_2017 shifts past bit 31 and mutates shared state in the reference; not built");
         return MDISP_E_UNSUPPORTED;

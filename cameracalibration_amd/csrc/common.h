@@ -69,7 +69,8 @@ __host__ __device__ static inline int md_align_dev(int v, int a) { return (v + a
 // census.hip
 int md_pad_reflect_lr(hipStream_t s, const u8* src, size_t spitch, int H, int W, int left, int right, u8* dst, size_t dpitch);
 int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int method, int arg, u8* dst, size_t dpitch,
-              u8* scratch /* H*W bytes, needed by the MULTISCALE variants */);
+              u8* scratch /* H*dpitch (rounded up to 256) + MD_CENSUS_SCRATCH_TAIL bytes, needed by the MULTISCALE variants */);
+#define MD_CENSUS_SCRATCH_TAIL 2048
 int md_hamming(hipStream_t s, const u8* a, size_t ap, const u8* b, size_t bp, int H, int W, int32_t* dst, size_t dp);
 int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch);
 

@@ -46,6 +46,7 @@ inline void countCensusImg_circle(cv::Mat src, cv::Mat& dst, int radius, int sam
 inline void countCensusImg_rotationInv(cv::Mat src, cv::Mat& dst) { mdisp::countCensusImg_rotationInv(src, dst); }
 inline void countCensusImg_uniform(cv::Mat src, cv::Mat& dst) { mdisp::countCensusImg_uniform(src, dst); }
 inline void countCensusImg_multiScale(cv::Mat src, cv::Mat& dst, int scale) { mdisp::countCensusImg_multiScale(src, dst, scale); }
+inline void countCensusImg_multiScale2(cv::Mat src, cv::Mat& dst, int scale) { mdisp::countCensusImg_multiScale2(src, dst, scale); }
 inline void countHummingDist(cv::Mat src1, cv::Mat src2, cv::Mat& dst) { mdisp::countHummingDist(src1, src2, dst); }
 inline cv::Mat censusStereo(StereoMatchParam param, CENSUS_ALGORITHM method) { return mdisp::censusStereo(param, method); }
 inline cv::Mat asw_gifs(StereoMatchParam param, double eps, GIF_TYPE gifType = GIF, int r2 = 5, double namda = 0.1, double h = 0.5)

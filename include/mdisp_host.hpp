@@ -169,6 +169,7 @@ template <class M> void countCensusImg(M src, M& dst, CENSUS_ALGORITHM method = 
 template <class M> void countCensusImg_rotationInv(M src, M& dst) { countCensusImg(src, dst, ROTATION_INVARIANT_CENSUS); }
 template <class M> void countCensusImg_uniform(M src, M& dst) { countCensusImg(src, dst, UNIFORM_CENSUS); }
 template <class M> void countCensusImg_multiScale(M src, M& dst, int scale) { countCensusImg(src, dst, MULTISCALE_CENSUS, scale); }
+template <class M> void countCensusImg_multiScale2(M src, M& dst, int scale) { countCensusImg(src, dst, STATISTIC_MULTISCALE_CENSUS, scale); }
 template <class M> void countCensusImg_circle(M src, M& dst, int radius, int samplePtNum = 8)
 {
     if (samplePtNum != 8) throw Error(MDISP_E_UNSUPPORTED, "countCensusImg_circle: only 8 sample points are built");

@@ -41,6 +41,16 @@ def test_census_multiscale_and_circle(api, orc, shape):
         assert np.array_equal(api.countCensusImg_multiScale(img, scale), orc.census(img, orc.MULTISCALE_CENSUS, scale))
     for radius in (2, 5):
         assert np.array_equal(api.countCensusImg_circle(img, radius), orc.census(img, orc.CIRCLE_CENSUS, radius))
+    for scale in (7, 16):
+        assert np.array_equal(api.countCensusImg_multiScale2(img, scale), orc.census(img, orc.STATISTIC_MULTISCALE_CENSUS, scale))
+
+
+def test_census_statistic_multiscale_ties(api, orc):
+    # few distinct codes: many histogram bins tie at zero, which exercises the "later rank overwrites" rule
+    img = np.zeros((40, 60), dtype=np.uint8)
+    img[:, 30:] = 200
+    img[10:20, 5:25] = 90
+    assert np.array_equal(api.countCensusImg_multiScale2(img, 9), orc.census(img, orc.STATISTIC_MULTISCALE_CENSUS, 9))
 
 
 def test_census_bgr_input_goes_through_gray(api, orc):
@@ -68,7 +78,7 @@ def test_census_stereo_integer_modes(api, orc, left, agg, shape, win, minD, maxD
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("method", [2, 3, 4, 1])
+@pytest.mark.parametrize("method", [2, 3, 4, 1, 5])
 def test_census_stereo_variants(api, orc, method):
     L, R = rand_pair(12, 60, 90, 16)
     for left in (True, False):
