@@ -40,7 +40,7 @@ EXPORTS = [
     "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_sgbm_volume", "mdisp_lr_check",
     "mdisp_build_rectify_maps", "mdisp_stereo_rectify", "mdisp_remap", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
-    "mdisp_census_stereo_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
+    "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
 ]
 
 _lib = None
@@ -90,6 +90,8 @@ def load():
     lib.mdisp_sgbm_batch_workspace_bytes.restype = C.c_size_t
     lib.mdisp_sgbm_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_census_stereo_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
+    lib.mdisp_asw_gifs_band_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_double, C.c_int, C.c_int, C.c_double,
+                                            C.c_int, C.c_int, C.c_int, vp]
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
     lib.mdisp_synth_pair.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]

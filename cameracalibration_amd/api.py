@@ -188,6 +188,15 @@ def asw_gifs(param, eps, gifType=GIF, r2=5, namda=0.1, h=0.5, cost_source=COST_C
     return _pair_call(fn, param, np.float32, ctx)
 
 
+def asw_gifs_band_dev(d_left, d_right, rows, cols, pitch, winSize, minDisparity, maxDisparity, isDispLeft, eps, gifType, r2, namda,
+                      row_begin, row_end, d_disp, cost_source=COST_CENSUS, ctx=None):
+    """asw_gifs on device-resident images (raw device pointers), output rows [row_begin, row_end) only:
+    one GPU's share of a pair that is sharded by horizontal row bands.  d_disp: float32 rows x cols."""
+    p = mdisp_param(winSize, minDisparity, maxDisparity, 1 if isDispLeft else 0)
+    check(load().mdisp_asw_gifs_band_dev(_ctx(ctx), d_left, d_right, rows, cols, pitch, C.byref(p), eps, gifType, r2, namda,
+                                         cost_source, row_begin, row_end, d_disp))
+
+
 def sgbm_params(minDisparity=0, numDisparities=64, P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=0, paths=8,
                 subpixel=1, costWin=1, censusMethod=BASIC_CENSUS):
     return mdisp_sgbm_params(minDisparity, numDisparities, P1, P2, uniquenessRatio, disp12MaxDiff, paths, subpixel,

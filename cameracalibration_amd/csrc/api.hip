@@ -464,6 +464,53 @@ extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
     return MDISP_OK;
 }
 
+// Device-resident asw_gifs restricted to the output rows [row_begin, row_end): what one GPU computes
+// when a large pair is sharded by row bands.  Both full images are resident on every GPU; everything
+// that is global to the image (guide statistics, steer weights, per-slice cost ranges) is recomputed
+// locally from them, so the bands need no exchange and are bit-identical to the rows of a full call.
+extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                       const mdisp_param* p, double eps, int gif_type, int r2, double namda, int cost_source,
+                                       int row_begin, int row_end, float* d_disp)
+{
+    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(rows > 0 && cols > 0 && pitch >= (size_t)cols && pitch % 4 == 0, MDISP_E_BADARG,
+               "bad geometry (pitch must be a multiple of 4 and >= cols)");
+    MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0 && p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity,
+               MDISP_E_BADARG, "bad function parameters, please check image and window size.");
+    MD_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= rows, MDISP_E_BADARG, "bad row band [%d, %d)", row_begin, row_end);
+    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_SKWGIF, MDISP_E_UNSUPPORTED,
+               "GIF type %d is not built (OURS_GIF* need the bilateral stage)", gif_type);
+    MD_REQUIRE(cost_source == MDISP_COST_CENSUS || cost_source == MDISP_COST_ABSDIFF, MDISP_E_BADARG,
+               "the band entry point forms its cost slices on the device (census or absdiff)");
+    if (row_begin == row_end) return MDISP_OK;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = rows, W = cols, maxD = p->maxDisparity, minD = p->minDisparity, D = maxD - minD + 1, Wp = W + maxD;
+    const size_t pitchP = md_align(Wp, 256);
+    Carver cv;
+    size_t o_pad = cv.take(pitchP * H), o_cr = cv.take(pitchP * H), o_cp = cv.take(pitchP * H);
+    size_t o_scr = cv.take(pitchP * H + MD_CENSUS_SCRATCH_TAIL), o_gif = cv.take(md_gif_scratch_bytes(H, W, D));
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    hipStream_t s = c->stream;
+    const u8* ref = p->isDispLeft ? d_left : d_right;
+    const u8* other = p->isDispLeft ? d_right : d_left;
+    int rc;
+    if (p->isDispLeft) rc = md_pad_reflect_lr(s, other, pitch, H, W, maxD, 0, base + o_pad, pitchP);
+    else rc = md_pad_reflect_lr(s, other, pitch, H, W, 0, maxD, base + o_pad, pitchP);
+    if (rc) return rc;
+    const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
+    const u8 *cr, *cp; size_t crp, cpp; int kind;
+    if (cost_source == MDISP_COST_CENSUS) {
+        if ((rc = md_census(s, ref, pitch, H, W, MDISP_BASIC_CENSUS, 0, base + o_cr, pitchP, base + o_scr))) return rc;
+        if ((rc = md_census(s, base + o_pad, pitchP, H, Wp, MDISP_BASIC_CENSUS, 0, base + o_cp, pitchP, base + o_scr))) return rc;
+        cr = base + o_cr; crp = pitchP; cp = base + o_cp; cpp = pitchP; kind = MD_COST_HAMMING;
+    } else {
+        cr = ref; crp = pitch; cp = base + o_pad; cpp = pitchP; kind = MD_COST_ABSDIFF;
+    }
+    return md_gif_stereo(c, base + o_gif, ref, pitch, H, W, D, minD, p->winSize, eps, gif_type, r2, namda, cr, crp, cp, cpp, off0, offStep,
+                         kind, nullptr, 0, d_disp, nullptr, row_begin, row_end);
+}
+
 // ---------------------------------------------------------------------------------------------
 // SGM
 

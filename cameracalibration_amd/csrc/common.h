@@ -112,7 +112,8 @@ int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, co
 size_t md_gif_scratch_bytes(int H, int W, int D);
 int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
                   int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
-                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64);
+                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64,
+                  int yA = -1, int yB = -1 /* output rows [yA, yB); default: the whole image */);
 
 // cost kinds of md_cost_box_wta
 enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };

@@ -335,14 +335,15 @@ __global__ __launch_bounds__(256) void ab_kernel(float* __restrict__ meanP_b, fl
 struct OutArgs {
     const float* v;                                       // filtered slices (a_bar*G + b_bar), or null to form them here
     const float* abar; const float* bbar; const float* G; size_t N; int n;
+    size_t i0, i1;                                        // pixel range [i0, i1) to process
     float* filtered; float* beta;
     float* best; float* disp32; double* disp64; int d0;   // d0 = disparity of the batch's first slice
     int first;                                            // 1: the running best is uninitialised
 };
 __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.N) return;
+    const size_t i = a.i0 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.i1) return;
     const float g = a.v ? 0.f : a.G[i];
     float best = 0.f; int bestd = 0; bool have = false;
     if (a.best && !a.first) { best = a.best[i]; have = true; bestd = a.disp32 ? (int)a.disp32[i] : (int)a.disp64[i]; }
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 // Window: starts at p - ksz/2; mode 0: ksz taps, BORDER_REFLECT_101; mode 1: 2*(ksz/2) taps, zero
 // outside [0, n-1) (the clipped half-open window of getGuidedFilter_skwgif2, gifs.cpp:591-592).
 #define MW 128
-struct MarchGeom { int H, W, ksz, mode, band; };
+struct MarchGeom { int H, W, ksz, mode, band; int yA, yB; };   // output rows [yA, yB) of the image
 
 template <class Load, class Store>
 __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld, Store st)
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
     const int a = g.ksz / 2;
     const int taps = g.mode == 0 ? g.ksz : 2 * a;
     const int rowW = MW + taps - 1;                       // <= 2 * MW: two elements per thread
-    const int x0 = blockIdx.x * MW, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
+    const int x0 = blockIdx.x * MW, y0 = g.yA + blockIdx.y * g.band, y1 = min(g.yB, y0 + g.band), k = blockIdx.z;
     const int tx = threadIdx.x, x = x0 + tx, wave = tx >> 6, lane = tx & 63;
     ld.begin(k);
     // the two row elements this thread loads: tx and tx + MW; source column and validity fixed per thread
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, L
     __shared__ __attribute__((aligned(16))) float row0[ROWP];
     __shared__ __attribute__((aligned(16))) float row1[ROWP];
     const int H = g.H, W = g.W;
-    const int x0 = blockIdx.x * MWF, y0 = blockIdx.y * g.band, y1 = min(H, y0 + g.band), k = blockIdx.z;
+    const int x0 = blockIdx.x * MWF, y0 = g.yA + blockIdx.y * g.band, y1 = min(g.yB, y0 + g.band), k = blockIdx.z;
     const int lane = threadIdx.x, c0 = 2 * lane, x = x0 + c0;
     ld.begin(k);
     // source columns of the (at most three) row elements this lane loads, reflected once
@@ -638,15 +639,18 @@ struct StoreOut {
 static bool march_supported(int ksz) { return ksz >= 1 && ksz <= MW; }    // a row and its halo are two elements per thread
 
 template <class Load, class Store>
-static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode, const Load& ld, const Store& st)
+static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode, int yA, int yB, const Load& ld, const Store& st)
 {
     const int taps = mode == 0 ? ksz : 2 * (ksz / 2);
     if (taps < 1) { mdisp_set_error("window %d too small", ksz); return MDISP_E_BADARG; }
     MarchGeom g;
     g.H = H; g.W = W; g.ksz = ksz; g.mode = mode;
     g.band = ksz <= 9 ? 64 : (ksz <= 21 ? 128 : 256);
+    g.yA = yA; g.yB = yB;
+    if (yB <= yA) return MDISP_OK;
+    const int nbands = (yB - yA + g.band - 1) / g.band;
     if (mode == 0 && (ksz == 3 || ksz == 5 || ksz == 7 || ksz == 9)) {
-        dim3 grid((W + MWF - 1) / MWF, (H + g.band - 1) / g.band, n);
+        dim3 grid((W + MWF - 1) / MWF, nbands, n);
         switch (ksz) {
         case 3: dual_box_march_small_kernel<3, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
         case 5: dual_box_march_small_kernel<5, Load, Store><<<grid, 64, 0, s>>>(g, ld, st); break;
@@ -656,7 +660,7 @@ static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode,
         MD_HIP(hipGetLastError());
         return MDISP_OK;
     }
-    dim3 grid((W + MW - 1) / MW, (H + g.band - 1) / g.band, n);
+    dim3 grid((W + MW - 1) / MW, nbands, n);
     dual_box_march_kernel<Load, Store><<<grid, MW, 0, s>>>(g, ld, st);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
@@ -924,7 +928,7 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
 // normalised and planar in sc.F0 (cs == null) or as integer costs formed on the fly (cs != null,
 // normalised with the per-slice min/max in mm).  beta (nullable): a_bar/(1 - a_bar) of each slice.
 static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, int n, const CostSrc* cs, int k0, const u32* mm,
-                            int normMode, float* beta)
+                            int normMode, float* beta, int yA, int yB)
 {
     hipStream_t s = c->stream;
     const int H = gs.H, W = gs.W, r = gs.r;
@@ -935,20 +939,23 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
         mdisp_set_error("guided-filter window above %d is not supported", MW);
         return MDISP_E_UNSUPPORTED;
     }
+    // output rows [yA, yB): the second filter reads a and b up to one window above and below them
+    const int k2 = skw ? gs.r2 : r;
+    const int yA1 = yA - k2 < 0 ? 0 : yA - k2, yB1 = yB + k2 > H ? H : yB + k2;
     // (P, G*P) -> means -> a -> F1, b -> F2   (gifs.cpp:60-61,71,96,127-128)
     StoreAB sab{sc.F1, sc.F2, N, W, gs.meanG, gs.den, 1.0 / ((double)r * r)};
     if (cs) {
         LoadCostGP ld{*cs, k0, mm, normMode, gs.G, {}};
-        if ((rc = dual_box_march(s, n, H, W, r, 0, ld, sab))) return rc;
+        if ((rc = dual_box_march(s, n, H, W, r, 0, yA1, yB1, ld, sab))) return rc;
     } else {
         LoadPlanarGP ld{sc.F0, N, W, gs.G};
-        if ((rc = dual_box_march(s, n, H, W, r, 0, ld, sab))) return rc;
+        if ((rc = dual_box_march(s, n, H, W, r, 0, yA1, yB1, ld, sab))) return rc;
     }
     // (a, b) -> means -> a_bar*G + b_bar -> F0; SKWGIF: steer-weighted means boxsum(w*a)/boxsum(w)
     // over the clipped r2 window (gifs.cpp:587-611)
     LoadAB lab{sc.F1, sc.F2, N, W, skw ? gs.w : nullptr};
     StoreOut so{sc.F0, N, W, gs.G, 1.0 / ((double)r * r), skw ? gs.wsum : nullptr, beta};
-    if ((rc = dual_box_march(s, n, H, W, skw ? gs.r2 : r, skw ? 1 : 0, lab, so))) return rc;
+    if ((rc = dual_box_march(s, n, H, W, k2, skw ? 1 : 0, yA, yB, lab, so))) return rc;
     return MDISP_OK;
 }
 
@@ -1059,7 +1066,7 @@ extern "C" int mdisp_guided_filter(mdisp_ctx* c, const mdisp_image* guide, const
         minmax_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm);
         normalize_kernel<float><<<g1, 256, 0, s>>>((const float*)rawP, N, mm, NORM_FLOAT, sc.F0);
     }
-    if ((rc = gif_filter_batch(c, gs, sc, 1, nullptr, 0, nullptr, NORM_FLOAT, beta ? dBeta : nullptr))) return rc;
+    if ((rc = gif_filter_batch(c, gs, sc, 1, nullptr, 0, nullptr, NORM_FLOAT, beta ? dBeta : nullptr, 0, H))) return rc;
     dOut = sc.F0;
     MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, dOut, (size_t)W * 4, (size_t)W * 4, H));
     if (beta) MD_TRY(md_d2h_2d(c, beta->data, beta->step_bytes, dBeta, (size_t)W * 4, (size_t)W * 4, H));
@@ -1078,9 +1085,10 @@ size_t md_gif_scratch_bytes(int H, int W, int D)
 
 int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
                   int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
-                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64)
+                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64, int yA, int yB)
 {
     hipStream_t s = c->stream;
+    if (yA < 0) { yA = 0; yB = H; }
     const size_t N = (size_t)H * W;
     const int n = pick_batch(N, D);
     Carve2 cv{(u8*)scratch};
@@ -1113,11 +1121,12 @@ int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, 
             cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part);
             cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
         }
-        if ((rc = gif_filter_batch(c, gs, sc, nb, hostCosts ? nullptr : &cs, k0, sc.mm + 2, normMode, nullptr))) return rc;
+        if ((rc = gif_filter_batch(c, gs, sc, nb, hostCosts ? nullptr : &cs, k0, sc.mm + 2, normMode, nullptr, yA, yB))) return rc;
         OutArgs oa;
         oa.v = sc.F0; oa.abar = nullptr; oa.bbar = nullptr; oa.G = gs.G; oa.N = N; oa.n = nb; oa.filtered = nullptr; oa.beta = nullptr;
         oa.best = best; oa.disp32 = dDisp32; oa.disp64 = dDisp64; oa.d0 = minD + k0; oa.first = k0 == 0;
-        out_wta_kernel<<<nblk(N), 256, 0, s>>>(oa);
+        oa.i0 = (size_t)yA * W; oa.i1 = (size_t)yB * W;
+        out_wta_kernel<<<nblk(oa.i1 - oa.i0), 256, 0, s>>>(oa);
         MD_HIP(hipGetLastError());
     }
     return MDISP_OK;

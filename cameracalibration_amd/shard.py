@@ -1,4 +1,4 @@
-"""Partition of a batch of stereo pairs over ranks (one process per GPU).
+"""Partition of work over ranks (one process per GPU): stereo pairs of a batch, or row bands of one large pair.
 
 Pairs are independent, so the data path needs no collective: every rank processes its own
 contiguous block of pairs; only the wall-clock of the slowest rank is reduced (MAX) to report
@@ -35,3 +35,32 @@ def slowest_rank_seconds(elapsed, dist=None, device=None):
 def job_throughput(units_per_pair, pairs_done_all_ranks, seconds):
     """Whole-job rate in Mdisp/s."""
     return units_per_pair * pairs_done_all_ranks / seconds / 1e6
+
+
+def row_band(rows, rank, world):
+    """Rows [begin, end) of an image of `rows` rows owned by `rank`: contiguous bands that differ by at
+    most one row and tile the image (same rule as pair_block)."""
+    first, count = pair_block(rows, rank, world)
+    return first, first + count
+
+
+def gather_row_bands(band, rows, dist=None):
+    """Assemble the full map from every rank's band.  `band` is this rank's (end - begin) x cols
+    torch tensor; the result (on every rank) is rows x cols.  Bands differ in height by at most one
+    row, so they are padded to a common height for all_gather and trimmed afterwards.  This is the
+    one exchange step of the row-band scheme: outputs only, no halo traffic."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert band.shape[0] == rows
+        return band
+    world = dist.get_world_size()
+    tall = max(row_band(rows, r, world)[1] - row_band(rows, r, world)[0] for r in range(world))
+    padded = torch.zeros((tall,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
+    padded[:band.shape[0]] = band
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    out = []
+    for r in range(world):
+        b, e = row_band(rows, r, world)
+        out.append(parts[r][:e - b])
+    return torch.cat(out, dim=0)

@@ -219,6 +219,16 @@ int mdisp_sgbm_batch_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_rig
 int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                             const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
 
+/* asw_gifs (methods_disp.h:66) on device buffers, restricted to the output rows [row_begin, row_end):
+ * the share of one GPU when a large pair is split into horizontal row bands.  d_left / d_right hold
+ * the WHOLE images (every GPU keeps a copy); d_disp is a float rows x cols map of which only the
+ * band's rows are written.  Rows are bit-identical to those of a full-image call: every quantity
+ * that is global to the image is recomputed locally, so bands need no exchange.  cost_source is
+ * MDISP_COST_CENSUS or MDISP_COST_ABSDIFF. */
+int mdisp_asw_gifs_band_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                            const mdisp_param* p, double eps, int gif_type, int r2, double namda, int cost_source,
+                            int row_begin, int row_end, float* d_disp);
+
 /* time of the most recent call's dominant kernel on this context, measured with HIP events on
  * the context's stream (milliseconds); which = 0: whole call, 1: SGM path aggregation (every scan
  * and sweep kernel of the call), 2: the separate winner-take-all kernel of the per-direction

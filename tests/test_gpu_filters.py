@@ -117,3 +117,32 @@ def test_asw_gifs(api, orc, gif, source):
     assert (got == exp).mean() > 0.999
     assert _tie_aware_equal(got, exp, filt, minD)
     assert D == filt.shape[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gif,win,r2", [(0, 7, 5), (3, 9, 15), (2, 11, 5), (3, 35, 15)])
+def test_row_bands_equal_the_full_image(api, gif, win, r2):
+    # the row-band entry point (one GPU's share of a large pair) reproduces the rows of a full call bit for bit
+    import torch
+    H, W, D = 97, 150, 24
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    pitch = W
+    if pitch % 4:
+        pitch = (W + 3) // 4 * 4
+        dl = torch.nn.functional.pad(dl, (0, pitch - W)).contiguous()
+        dr = torch.nn.functional.pad(dr, (0, pitch - W)).contiguous()
+
+    def run(bands):
+        out = torch.full((H, W), -1.0, dtype=torch.float32, device="cuda")
+        for (b, e) in bands:
+            api.asw_gifs_band_dev(dl.data_ptr(), dr.data_ptr(), H, W, pitch, win, 0, D - 1, True, 0.01, gif, r2, 0.1, b, e, out.data_ptr())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    full = run([(0, H)])
+    assert full.min() >= 0
+    p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=win, minDisparity=0, maxDisparity=D - 1, isDispLeft=True)
+    assert np.array_equal(full, api.asw_gifs(p, 0.01, gif, r2, 0.1, 0.5, api.COST_CENSUS))
+    for bands in ([(0, 48), (48, 97)], [(0, 3), (3, 50), (50, 96), (96, 97)], [(0, 33), (33, 65), (65, 97)]):
+        assert np.array_equal(run(bands), full)

@@ -68,3 +68,46 @@ def test_two_ranks_gloo():
     assert [r[2] for r in res] == [2.0, 2.0]        # both ranks see the slowest rank's time
     assert sum(r[3] for r in res) == 13
     assert shard.job_throughput(1920 * 1080 * 256, 13, 2.0) == pytest.approx(1920 * 1080 * 256 * 13 / 2.0 / 1e6)
+
+
+def test_row_bands_tile_the_image():
+    for rows in (1, 7, 1080, 4320):
+        for world in (1, 2, 3, 8):
+            edges = [shard.row_band(rows, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == rows
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows, cols = 11, 5                       # odd height: the bands differ by one row
+        full = torch.arange(rows * cols, dtype=torch.float32).reshape(rows, cols)
+        b, e = shard.row_band(rows, rank, world)
+        got = shard.gather_row_bands(full[b:e].clone(), rows, dist)
+        q.put((rank, bool(torch.equal(got, full)), (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_band_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == (0, 6) and res[1][2] == (6, 11)
