@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the dense-stereo hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): synthetic rectified
+Workload (the configuration the headline metric is quoted on): synthetic rectified
 1920x1080 pairs, D = 256, census -> Hamming cost -> SGM 8-path aggregation -> WTA + uniqueness +
 x16 sub-pixel + LR check, inputs resident in HBM, through the C ABI (mdisp_sgbm_dev).
-One "step" = one batch of `--pairs` stereo pairs per GPU (default 64: BASELINE.json's batch of 512 pairs over 8 GPUs).  With N GPUs every rank processes its own
+One "step" = one batch of `--pairs` stereo pairs per GPU (default 64: a batch of 512 pairs split over 8 GPUs).  With N GPUs every rank processes its own
 batch (pairs are independent: no collective on the data path) -> weak scaling.
 
 Prints ONE JSON line on rank 0."""

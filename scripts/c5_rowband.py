@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Large single pair, row-band sharded (BASELINE.json configs[4]): 7680x4320, D=512, steer-weighted guided
+"""Large single pair, row-band sharded: 7680x4320, D=512, steer-weighted guided
 aggregation (winSize 35, r2 15, eps 0.01), one process per GPU.
 
 Every rank holds both full images, computes the disparity rows of its band with mdisp_asw_gifs_band_dev and the
