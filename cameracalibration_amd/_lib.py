@@ -38,7 +38,7 @@ EXPORTS = [
     "mdisp_version", "mdisp_last_error", "mdisp_device_count", "mdisp_create", "mdisp_destroy", "mdisp_synchronize",
     "mdisp_census_transform", "mdisp_hamming_dist", "mdisp_census_stereo", "mdisp_sad_inte", "mdisp_sad_box",
     "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_sgbm_volume", "mdisp_lr_check",
-    "mdisp_build_rectify_maps", "mdisp_stereo_rectify", "mdisp_remap", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
+    "mdisp_build_rectify_maps", "mdisp_stereo_rectify", "mdisp_remap", "mdisp_reproject_q", "mdisp_reproject_triangulate", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
 ]
@@ -82,6 +82,8 @@ def load():
     dp = P(C.c_double)
     lib.mdisp_stereo_rectify.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double,
                                          dp, dp, dp, dp, dp, P(C.c_int), P(C.c_int)]
+    lib.mdisp_reproject_q.argtypes = [vp, img, dp, img]
+    lib.mdisp_reproject_triangulate.argtypes = [vp, img, dp, C.c_double, img, img]
     lib.mdisp_remap.argtypes = [vp, img, vp, vp, img]
     lib.mdisp_sgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, sgp]
     lib.mdisp_sgbm_workspace_bytes.restype = C.c_size_t

@@ -296,6 +296,26 @@ def remap(src, map1, map2, ctx=None):
     return dst
 
 
+def reprojectQ(disparityMap, Q, ctx=None):
+    """methods/methods.cpp:2039-2076: Q * (row, col, d, 1), divided by W and by 100 -> H x W x 3 float32."""
+    d = np.ascontiguousarray(disparityMap, dtype=np.float32)
+    Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(16)
+    xyz = np.empty(d.shape + (3,), dtype=np.float32)
+    check(load().mdisp_reproject_q(_ctx(ctx), C.byref(image(d)), Q.ctypes.data_as(C.POINTER(C.c_double)), C.byref(image(xyz))))
+    return xyz
+
+
+def reprojectTriangulate(disparityMap, K_new, baseline, originBGRMap=None, ctx=None):
+    """methods/methods.cpp:2300-2352 -> H x W x 3 float32 (points that the reference skips stay zero)."""
+    d = np.ascontiguousarray(disparityMap, dtype=np.float32)
+    K = np.ascontiguousarray(K_new, dtype=np.float64).reshape(9)
+    xyz = np.empty(d.shape + (3,), dtype=np.float32)
+    bgr = np.ascontiguousarray(originBGRMap, dtype=np.float32) if originBGRMap is not None else None
+    check(load().mdisp_reproject_triangulate(_ctx(ctx), C.byref(image(d)), K.ctypes.data_as(C.POINTER(C.c_double)), float(baseline),
+                                             C.byref(image(bgr)) if bgr is not None else None, C.byref(image(xyz))))
+    return xyz
+
+
 def synth_pair(seed, rows, cols, numDisp):
     """Synthetic rectified pair (left, right, ground-truth disparity)."""
     left = np.empty((rows, cols), dtype=np.uint8)

@@ -512,6 +512,52 @@ extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// disparity -> 3-D points
+
+static int reproject_common(mdisp_ctx* c, const mdisp_image* disp, const mdisp_image* bgr, mdisp_image* xyz, const double* Q,
+                            const double* K, double baseline)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(disp, "disparity"))) return rc;
+    MD_REQUIRE(disp->depth == MDISP_32F && disp->channels == 1, MDISP_E_BADARG, "the disparity map must be CV_32FC1");
+    if ((rc = check_out(xyz, disp->rows, disp->cols, MDISP_32F, 3, "xyz"))) return rc;
+    if (bgr) {
+        if ((rc = check_image(bgr, "colour image"))) return rc;
+        MD_REQUIRE(bgr->depth == MDISP_32F && bgr->channels == 3 && bgr->rows == disp->rows && bgr->cols == disp->cols, MDISP_E_BADARG,
+                   "the colour image must be CV_32FC3 of the disparity's size");
+    }
+    MD_HIP(hipSetDevice(c->device));
+    const int H = disp->rows, W = disp->cols;
+    Carver cv;
+    size_t o_d = cv.take((size_t)H * W * 4), o_c = cv.take(bgr ? (size_t)H * W * 12 : 0), o_x = cv.take((size_t)H * W * 12);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base + o_d, (size_t)W * 4, disp->data, disp->step_bytes, (size_t)W * 4, H));
+    if (bgr) MD_TRY(md_h2d_2d(c, base + o_c, (size_t)W * 12, bgr->data, bgr->step_bytes, (size_t)W * 12, H));
+    if (Q) rc = md_reproject_q(c->stream, (const float*)(base + o_d), H, W, Q, (float*)(base + o_x));
+    else rc = md_reproject_tri(c->stream, (const float*)(base + o_d), H, W, K, baseline, bgr ? (const float*)(base + o_c) : nullptr,
+                               (float*)(base + o_x));
+    if (rc) return rc;
+    MD_TRY(md_d2h_2d(c, xyz->data, xyz->step_bytes, base + o_x, (size_t)W * 12, (size_t)W * 12, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_reproject_q(mdisp_ctx* c, const mdisp_image* disp, const double Q[16], mdisp_image* xyz)
+{
+    MD_REQUIRE(Q, MDISP_E_BADARG, "null Q");
+    return reproject_common(c, disp, nullptr, xyz, Q, nullptr, 0.0);
+}
+
+extern "C" int mdisp_reproject_triangulate(mdisp_ctx* c, const mdisp_image* disp, const double K[9], double baseline,
+                                           const mdisp_image* bgr, mdisp_image* xyz)
+{
+    MD_REQUIRE(K, MDISP_E_BADARG, "null camera matrix");
+    return reproject_common(c, disp, bgr, xyz, nullptr, K, baseline);
+}
+
+// ---------------------------------------------------------------------------------------------
 // SGM
 
 extern "C" size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p)

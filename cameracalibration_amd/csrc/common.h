@@ -108,6 +108,9 @@ int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, f
 int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
              int dH, int dW, u8* dst, size_t dp);
 
+int md_reproject_q(hipStream_t s, const float* disp, int H, int W, const double Q[16], float* xyz);
+int md_reproject_tri(hipStream_t s, const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz);
+
 // filters.hip: guided-filter aggregation of D cost slices + first-minimum WTA
 size_t md_gif_scratch_bytes(int H, int W, int D);
 int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,

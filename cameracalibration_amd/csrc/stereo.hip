@@ -343,3 +343,70 @@ int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, co
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Disparity -> 3-D points (cameraCalibration/methods/methods.cpp:2039-2076 and :2300-2352), double
+// arithmetic per pixel, float output (x, y, z interleaved as in pcl::PointXYZ).
+struct Mat44 { double m[16]; };
+__global__ __launch_bounds__(256) void reproject_q_kernel(const float* __restrict__ disp, int H, int W, Mat44 Q, float* __restrict__ xyz)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;     // the reference multiplies Q by (row, col, d, 1)
+    if (v >= W) return;
+    const double d = (double)disp[(size_t)u * W + v];
+    double X = 0, Y = 0, Z = 0;
+    if (d != 0) {
+        const double in[4] = {(double)u, (double)v, d, 1.0};
+        double o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s = __dadd_rn(s, __dmul_rn(Q.m[i * 4 + k], in[k]));
+            o[i] = s;
+        }
+        X = __ddiv_rn(o[0], o[3]); Y = __ddiv_rn(o[1], o[3]); Z = __ddiv_rn(o[2], o[3]);
+    }
+    float* p = xyz + ((size_t)u * W + v) * 3;
+    p[0] = (float)__ddiv_rn(X, 100.0); p[1] = (float)__ddiv_rn(Y, 100.0); p[2] = (float)__ddiv_rn(Z, 100.0);
+}
+
+__global__ __launch_bounds__(256) void reproject_tri_kernel(const float* __restrict__ disp, int H, int W, double f0, double f1, double u0,
+                                                            double v0, double baseline, const float* __restrict__ bgr,
+                                                            float* __restrict__ xyz)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= W) return;
+    const double dv = __dsub_rn((double)v, v0);
+    const double temp1 = __dadd_rn(__dmul_rn(dv, dv), __dmul_rn(f1, f1));
+    const double coeff = __ddiv_rn(__dmul_rn(f0, f1), sqrt(temp1));
+    const double px0 = __ddiv_rn(__dsub_rn((double)u, u0), f0), px1 = __ddiv_rn(dv, f1);
+    const double d = (double)disp[(size_t)v * W + u];
+    double X = 0, Y = 0, Z = 0;
+    if (d != 0) {
+        Z = __ddiv_rn(__dmul_rn(baseline, coeff), fabs(d));
+        Y = __dmul_rn(px1, Z);
+        X = __dmul_rn(px0, sqrt(__dadd_rn(__dmul_rn(Z, Z), __dmul_rn(Y, Y))));
+    }
+    float* p = xyz + ((size_t)v * W + u) * 3;
+    bool keep = !(Z > 20000);
+    if (keep && bgr) {
+        const float* c = bgr + ((size_t)v * W + u) * 3;
+        keep = !(c[0] == 0 && c[1] == 0 && c[2] == 0);
+    }
+    p[0] = keep ? (float)X : 0.f; p[1] = keep ? (float)Y : 0.f; p[2] = keep ? (float)Z : 0.f;
+}
+
+int md_reproject_q(hipStream_t s, const float* disp, int H, int W, const double Q[16], float* xyz)
+{
+    Mat44 q;
+    memcpy(q.m, Q, sizeof q.m);
+    reproject_q_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(disp, H, W, q, xyz);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+int md_reproject_tri(hipStream_t s, const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz)
+{
+    reproject_tri_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(disp, H, W, K[0], K[4], K[2], K[5], baseline, bgr, xyz);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}

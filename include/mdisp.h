@@ -196,6 +196,16 @@ int mdisp_stereo_rectify(const double K1[9], const double* D1, const double K2[9
  * src/dst CV_8UC1 or CV_8UC3; maps as produced above, of dst's size. */
 int mdisp_remap(mdisp_ctx*, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst);
 
+/* Disparity -> 3-D points, the step downstream of the disparity routines.
+ * mdisp_reproject_q: methods/methods.cpp:2039-2076 -- [X Y Z W] = Q * [row col d 1] (row index first, as the
+ *   reference writes it), point = (X/W, Y/W, Z/W) / 100; zero where the disparity is 0.
+ * mdisp_reproject_triangulate: methods/methods.cpp:2300-2352 -- depth from the baseline and K_new with the
+ *   row-dependent focal coefficient; points beyond 20000 or (when bgr is given) with a black colour stay zero.
+ * disp CV_32FC1, bgr CV_32FC3 or NULL, xyz CV_32FC3 (x, y, z interleaved, what the PCD writer stores). */
+int mdisp_reproject_q(mdisp_ctx*, const mdisp_image* disp, const double Q[16], mdisp_image* xyz);
+int mdisp_reproject_triangulate(mdisp_ctx*, const mdisp_image* disp, const double K[9], double baseline,
+                                const mdisp_image* bgr, mdisp_image* xyz);
+
 /* ---- device-resident entry points (inputs already in HBM, nothing copied, no sync) ---- */
 
 /* bytes of device workspace mdisp_sgbm_dev needs for one pair */

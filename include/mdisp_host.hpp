@@ -272,6 +272,25 @@ template <class M> void rectifyImage(M src, const double K[9], const double* dis
     detail::check(mdisp_remap(Context::forThisThread().handle(), &s, m1.data(), m2.data(), &d));
 }
 
+// disparity -> 3-D points (methods/methods.cpp:2039-2076 and :2300-2352); xyz is CV_32FC3
+template <class M> void reprojectQ(M disparityMap, const double Q[16], M& xyz)
+{
+    typedef mat_traits<M> T;
+    mdisp_image d = T::view(disparityMap);
+    T::create(xyz, d.rows, d.cols, MDISP_32F, 3);
+    mdisp_image o = T::view(xyz);
+    detail::check(mdisp_reproject_q(Context::forThisThread().handle(), &d, Q, &o));
+}
+template <class M> void reprojectTriangulate(M disparityMap, const double K_new[9], double baseline, const M* originBGRMap, M& xyz)
+{
+    typedef mat_traits<M> T;
+    mdisp_image d = T::view(disparityMap), c;
+    if (originBGRMap) c = T::view(*originBGRMap);
+    T::create(xyz, d.rows, d.cols, MDISP_32F, 3);
+    mdisp_image o = T::view(xyz);
+    detail::check(mdisp_reproject_triangulate(Context::forThisThread().handle(), &d, K_new, baseline, originBGRMap ? &c : nullptr, &o));
+}
+
 typedef StereoMatchParamT<Mat> StereoMatchParam;
 
 }  // namespace mdisp

@@ -120,6 +120,10 @@ void orc_stereo_rectify(const double K1[9], const double* D1, const double K2[9]
                         int global_rotation, double R1[9], double R2[9], double P1[12], double P2[12], double Q[16],
                         int roi1[4], int roi2[4]);
 
+/* ---- disparity -> 3-D points ---- */
+void orc_reproject_q(const float* disp, int H, int W, const double Q[16], float* xyz);
+void orc_reproject_triangulate(const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,3 +272,25 @@ def stereo_rectify(K1, D1, K2, D2, size, R, T, alpha=-1.0, zero_disparity=True, 
        _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), _p(roi1), _p(roi2))
     return {"R1": R1.reshape(3, 3), "R2": R2.reshape(3, 3), "P1": P1.reshape(3, 4), "P2": P2.reshape(3, 4),
             "Q": Q.reshape(4, 4), "roi1": tuple(int(v) for v in roi1), "roi2": tuple(int(v) for v in roi2)}
+
+
+def reproject_q(disp, Q):
+    disp = np.ascontiguousarray(disp, np.float32)
+    Q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    H, W = disp.shape
+    xyz = np.empty((H, W, 3), np.float32)
+    lib().orc_reproject_q(_p(disp), H, W, _p(Q), _p(xyz))
+    return xyz
+
+
+def reproject_triangulate(disp, K, baseline, bgr=None):
+    disp = np.ascontiguousarray(disp, np.float32)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    H, W = disp.shape
+    xyz = np.empty((H, W, 3), np.float32)
+    fn = lib().orc_reproject_triangulate
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    c = np.ascontiguousarray(bgr, np.float32) if bgr is not None else None
+    fn(_p(disp), H, W, _p(K), float(baseline), _p(c) if c is not None else None, _p(xyz))
+    return xyz

@@ -260,3 +260,21 @@ def test_sgm_full_size_frame_bit_exact(api, orc):
     valid = got >= 0
     assert valid.mean() > 0.6
     assert np.median(np.abs(got[valid] / 16.0 - gt[valid])) <= 1.0
+
+
+@pytest.mark.gpu
+def test_reprojection_to_3d(api, orc):
+    rng = np.random.default_rng(5)
+    H, W = 45, 70
+    disp = rng.integers(0, 64, (H, W)).astype(np.float32)
+    disp[rng.random((H, W)) < 0.2] = 0.0                      # holes stay at the origin
+    disp[3, 4] = 0.01                                          # far point: beyond the 20000 cut of the triangulation
+    Q = np.array([[1, 0, 0, -31.5], [0, 1, 0, -22.25], [0, 0, 0, 855.95], [0, 0, 6.55e-3, 0.0]])
+    assert np.array_equal(api.reprojectQ(disp, Q), orc.reproject_q(disp, Q))
+    K = np.array([[855.95, 0, 31.5], [0, 860.1, 22.25], [0, 0, 1.0]])
+    bgr = rng.integers(0, 3, (H, W, 3)).astype(np.float32)     # some pixels are black
+    for colour in (None, bgr):
+        got = api.reprojectTriangulate(disp, K, 152.63, colour)
+        exp = orc.reproject_triangulate(disp, K, 152.63, colour)
+        assert np.array_equal(got, exp)
+    assert not got[3, 4].any()

@@ -252,3 +252,18 @@ def test_lr_check_simple(orc):
     dR[:, 3] = 7
     vl, _ = orc.lr_check(dL, dR)
     assert not vl[:, 5].any() and vl[:, 6].all()
+
+
+def test_reprojection_known_answers(orc):
+    # one pixel by hand: Q * (row, col, d, 1) with the row index first, then / W / 100
+    Q = np.array([[1, 0, 0, -10.0], [0, 1, 0, -20.0], [0, 0, 0, 800.0], [0, 0, 0.01, 0.0]])
+    disp = np.zeros((4, 5), np.float32)
+    disp[2, 3] = 8.0
+    xyz = orc.reproject_q(disp, Q)
+    w = 0.01 * 8.0
+    assert np.allclose(xyz[2, 3], [(2 - 10.0) / w / 100, (3 - 20.0) / w / 100, 800.0 / w / 100], rtol=1e-6)
+    assert not xyz[0, 0].any()
+    # triangulation on the optical axis: Z = baseline * f0 / d
+    K = np.array([[500.0, 0, 3.0], [0, 500.0, 2.0], [0, 0, 1.0]])
+    p = orc.reproject_triangulate(disp, K, 100.0)[2, 3]
+    assert np.allclose(p, [0.0, 0.0, 100.0 * 500.0 / 8.0], rtol=1e-6)
