@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--paths", type=int, default=8, help="8 (the headline configuration) or 5 (StereoSGBM's default mode)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -87,7 +88,7 @@ def main():
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
     ctx = _lib.Context(device=local_rank, stream=stream)
-    params = api.sgbm_params(0, D, P1, P2, 10, 1, 8, 1)
+    params = api.sgbm_params(0, D, P1, P2, 10, 1, args.paths, 1)
 
     # synthetic inputs, resident in HBM before the timed region
     B = args.pairs
@@ -159,7 +160,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 D=256 census-Hamming cost + SGM 8-path + WTA/uniqueness + x16 subpixel + LR check",
+            "config": {"workload": f"1920x1080 D=256 census-Hamming cost + SGM {args.paths}-path + WTA/uniqueness + x16 subpixel + LR check",
                        "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -70,7 +70,8 @@ struct Sgm2Args {
     int H, W, D, minD, maxD, nstrips;
     u32 P1P1, P2P2;
     int tail;                             // 1 when D < 256: disparities >= D are masked off
-    int naturalOut;                       // up sweep: store S8 in natural d order (for the separate WTA kernel)
+    int naturalOut;                       // last sweep: store the full sum in natural d order (volume export)
+    int five;                             // 5-path mode (both horizontals + the three downward paths): the down sweep is the last one
     uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
     int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
 };
@@ -699,8 +700,10 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     };
     u32 Nr[NR];                        // the diagonal that stays in this sheared column
     fresh(Nr);
-    u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0);
+    u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0), hb2 = make_uint4(0, 0, 0, 0);
     u32 Snext[NR];
+    const bool five = !UP && a.five;   // this down sweep also adds the (-1,0) volume and finishes the sum
+    const u8* Hp2 = a.Hvol[1] + (size_t)pair * a.strideH;
     uint4 sb = make_uint4(0, 0, 0, 0);
     // S4B: the four-path partial sum fits a byte per disparity and travels as 256 bytes per pixel
     u8* Sb = reinterpret_cast<u8*>(Sp);
@@ -710,6 +713,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
             load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
             const size_t pix = (size_t)y * W + x;
             hb = load16_stream(Hp + pix * 256 + lic * 16);
+            if (five) hb2 = load16_stream(Hp2 + pix * 256 + lic * 16);
             if (UP) { if (S4B) sb = load16_stream(Sb + pix * 256 + lic * 16); else load8_stream(Sp + (pix * 256 + lic * DPL), Snext); }
         }
     };
@@ -724,6 +728,11 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         if (active) {
             cost_from_operands(cl, rb, C);
             unpack_bytes(hb, Sacc);
+            if (five) {
+                unpack_bytes(hb2, Snext);
+#pragma unroll
+                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+            }
             if (UP) {
                 if (S4B) unpack_bytes(sb, Snext);
 #pragma unroll
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
             *reinterpret_cast<uint4*>(&bs[par][m][lic * 4]) = pack_bytes(N);
             const size_t pix = (size_t)y * W + x;
             if (FUSE) fused_wta<TAIL>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
-            else if (UP && a.naturalOut) {
+            else if ((UP || five) && a.naturalOut) {
                 u32 nat[NR];
 #pragma unroll
                 for (int g = 0; g < NR / 2; g++) {
@@ -850,7 +859,7 @@ size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode)
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
 {
-    return pl.npaths == 8 && pl.D <= 256 && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 8192 &&
+    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && pl.D <= 256 && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 8192 &&
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 
@@ -883,6 +892,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.P2P2 = (u32)pl.P2 | ((u32)pl.P2 << 16);
     a.tail = pl.D < 256;
     a.naturalOut = naturalOut;
+    a.five = pl.npaths == 5;
     const size_t oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
     a.rec = (uint2*)(hbase + 2 * oneH * batch);
     a.strideRec = oneRec / sizeof(uint2);
@@ -905,7 +915,12 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         } while (0)
         // the down sweep's four-path sum stays below 256 for small P2: half the volume traffic
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-        if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
+        if (a.five) {
+            // -> and <- from the horizontal scan, the three downward paths and the winner-take-all in ONE sweep
+            sgm2_hscan_kernel<true, true><<<gh, 256, 0, s>>>(a);
+            if (naturalOut) sgm2_shear_kernel<false, true, false, false><<<gs, 320, 0, s>>>(sa);
+            else sgm2_shear_kernel<false, true, true, false><<<gs, 320, 0, s>>>(sa);
+        } else if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
         else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
 #undef SGM2_SHEAR
         MD_HIP(hipGetLastError());

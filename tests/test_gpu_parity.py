@@ -149,6 +149,9 @@ SGM_CASES = [
     (64, 200, 0, 256, 8, 47, 10, 1, 8, 1),      # largest P2 with byte partial sums
     (64, 200, 0, 256, 8, 48, 10, 1, 8, 1),      # smallest P2 without
     (90, 310, 0, 128, 8, 247, 10, 1, 8, 1),     # largest P2 with byte path states
+    (60, 300, 0, 256, 8, 32, 10, 1, 5, 1),      # five paths (StereoSGBM's default mode): one fused down sweep
+    (75, 40, 1, 20, 2, 5, 10, 1, 5, 0),
+    (50, 80, 0, 64, 20, 300, 10, 1, 5, 1),      # five paths with 16-bit path values: per-direction fallback
 ]
 
 
@@ -246,6 +249,9 @@ def test_sgm_volume_bit_exact(api, orc):
         S = api.sgbm_volume(L, R, api.sgbm_params(minD, D, P1, P2, 10, 1, 8, 1))
         _, E = orc.sgm(L, R, minD, D, P1, P2, 10, 1, 8, 1, want_S=True)
         assert np.array_equal(S, E)
+        S5 = api.sgbm_volume(L, R, api.sgbm_params(minD, D, P1, P2, 10, 1, 5, 1))
+        _, E5 = orc.sgm(L, R, minD, D, P1, P2, 10, 1, 5, 1, want_S=True)
+        assert np.array_equal(S5, E5)
 
 
 @pytest.mark.gpu
