@@ -54,6 +54,19 @@ def measured_traffic():
         return float(json.load(f)["traffic_bytes_per_pair"]), os.path.relpath(files[-1], ROOT)
 
 
+def measured_issue_bound():
+    """VALU wave-instructions per pair from the committed SQ counter pass (scripts/sq_summary.py): the kernels are
+    bound by VALU issue, not by HBM, so this is the ceiling that actually applies."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_issue.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {"valu_wave_instructions_per_pair": d["valu_instructions_per_pair"], "ms_per_pair_at_full_issue": d["issue_bound_ms_per_pair"],
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +182,10 @@ def main():
                          "ms_per_pair": pair_s * 1e3, "ms_aggregation_per_pair": float(np.mean(agg_ms)) / B,
                          "algorithmic_bytes_per_pair": alg_bytes},
         }
+        issue = measured_issue_bound()
+        if issue and args.paths == 8:
+            issue["frac"] = issue["ms_per_pair_at_full_issue"] / (pair_s * 1e3)
+            out["roofline"]["valu_issue_bound"] = issue
         if world == 1 and not args.no_cpu_baseline:
             from oracle import orc
             orc.build()
