@@ -39,7 +39,7 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->stage = nullptr; c->stage_bytes = 0;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_failed = false; c->stage = nullptr; c->stage_bytes = 0;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -75,11 +75,15 @@ extern "C" int mdisp_synchronize(mdisp_ctx* c)
 
 int md_check_sgm_error(mdisp_ctx* c)
 {
-    if (!c->sgm_err) return MDISP_OK;
-    int flag = 0;
-    const int* p = c->sgm_err;
-    c->sgm_err = nullptr;
-    MD_HIP(hipMemcpy(&flag, p, sizeof(int), hipMemcpyDeviceToHost));
+    int flag = c->sgm_failed ? 1 : 0;
+    c->sgm_failed = false;
+    if (c->sgm_err) {
+        const int* p = c->sgm_err;
+        c->sgm_err = nullptr;
+        int f = 0;
+        MD_HIP(hipMemcpy(&f, p, sizeof(int), hipMemcpyDeviceToHost));
+        flag |= f;
+    }
     MD_REQUIRE(flag == 0, MDISP_E_HIP, "SGM sweep pipeline: a strip waited too long for its neighbour (results are invalid)");
     return MDISP_OK;
 }
@@ -134,6 +138,12 @@ void* mdisp_ws(mdisp_ctx* c, size_t bytes)
     if (bytes <= c->ws_bytes) return c->ws;
     // the stream may still be reading the old block
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mdisp_set_error("stream sync failed"); return nullptr; }
+    if (c->sgm_err) {
+        // the error word may live in the block that is about to be released: read it now
+        int f = 0;
+        if (hipMemcpy(&f, c->sgm_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && f) c->sgm_failed = true;
+        c->sgm_err = nullptr;
+    }
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
     size_t want = md_align(bytes + bytes / 8, 1 << 20);
     if (hipMalloc(&c->ws, want) != hipSuccess) {

@@ -48,6 +48,7 @@ struct mdisp_ctx {
     void* stage;         // grow-only device staging buffer of the host<->device image copies
     size_t stage_bytes;
     const int* sgm_err;  // device error word of the last pipelined SGM call (0 = fine), or null
+    bool sgm_failed;     // an error word was set when it had to be read early (workspace about to be released)
 };
 // after the stream has been synchronised: fails if the last SGM call reported a hand-off timeout
 int md_check_sgm_error(mdisp_ctx* ctx);
