@@ -75,9 +75,13 @@ def main():
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--paths", type=int, default=8, help="8 (the headline configuration) or 5 (StereoSGBM's default mode)")
+    ap.add_argument("--disp", type=int, default=256, help="number of disparities (256 is the headline configuration; "
+                                                          "other values are side measurements)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+    global D
+    D = args.disp
 
     import torch
     import torch.distributed as dist
@@ -159,9 +163,9 @@ def main():
     achieved = alg_bytes / pair_s / 1e9
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = measured_traffic() if D == 256 and args.paths == 8 else (None, None)
         out = {
-            "metric": "Mdisp/s (WxHxD per sec) at 1920x1080, D=256",
+            "metric": f"Mdisp/s (WxHxD per sec) at 1920x1080, D={D}",
             "value": shard.job_throughput(units_per_pair, args.pairs * args.steps * world, elapsed),
             "unit": "Mdisp/s",
             "n_gpus": world,
@@ -173,7 +177,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic",
-            "config": {"workload": f"1920x1080 D=256 census-Hamming cost + SGM {args.paths}-path + WTA/uniqueness + x16 subpixel + LR check",
+            "config": {"workload": f"1920x1080 D={D} census-Hamming cost + SGM {args.paths}-path + WTA/uniqueness + x16 subpixel + LR check",
                        "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -183,7 +187,7 @@ def main():
                          "algorithmic_bytes_per_pair": alg_bytes},
         }
         issue = measured_issue_bound()
-        if issue and args.paths == 8:
+        if issue and args.paths == 8 and D == 256:
             issue["frac"] = issue["ms_per_pair_at_full_issue"] / (pair_s * 1e3)
             out["roofline"]["valu_issue_bound"] = issue
         if world == 1 and not args.no_cpu_baseline:

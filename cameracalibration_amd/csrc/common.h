@@ -88,7 +88,8 @@ struct md_sgm_plan {
 };
 // sgm2.hip
 bool md_sgm2_supported(const md_sgm_plan& pl);
-size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode);
+size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch);
+int md_sgm2_slots(const md_sgm_plan& pl);   // u16 elements per pixel of the S volume (64, 128 or 256)
 bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
                       u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord);

@@ -277,13 +277,13 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm
     plan->off_scratch = off; off += plan->pitchR * H;
     off = md_align(off, 256);
     plan->use_v2 = md_sgm2_supported(*plan) && !getenv("MDISP_SGM_V1");
-    plan->sstride = plan->use_v2 ? 256 : plan->D;
+    plan->sstride = plan->use_v2 ? md_sgm2_slots(*plan) : plan->D;
     plan->strideS = md_align((size_t)H * W * plan->sstride * sizeof(u16), 256) / sizeof(u16);
     plan->off_S = off; off += plan->strideS * sizeof(u16) * batch;
     off = md_align(off, 256);
     plan->off_aux = off; off += 4096;
     plan->off_bnd = off;
-    if (plan->use_v2) off += md_sgm2_extra_bytes(H, W, batch, md_sgm2_u8(*plan));
+    if (plan->use_v2) off += md_sgm2_extra_bytes(*plan, batch);
     plan->total = off;
     return MDISP_OK;
 }

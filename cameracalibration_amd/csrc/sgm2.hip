@@ -47,13 +47,14 @@ template <int CTRL> __device__ __forceinline__ u32 dpp_all(u32 v) { return (u32)
 template <int CTRL> __device__ __forceinline__ u32 dpp_keep(u32 old, u32 v)
 { return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false); }
 
-// minimum over the 16 lanes of a DPP row, result in every lane
+// minimum over the LPC (4, 8 or 16) aligned lanes that share a pixel, result in every one of them
+template <int LPC = 16>
 __device__ __forceinline__ u32 row_min16(u32 v)
 {
     v = min(v, dpp_all<DPP_XOR1>(v));
     v = min(v, dpp_all<DPP_XOR2>(v));
-    v = min(v, dpp_all<DPP_HALF_MIRROR>(v));
-    v = min(v, dpp_all<DPP_MIRROR>(v));
+    if (LPC >= 8) v = min(v, dpp_all<DPP_HALF_MIRROR>(v));
+    if (LPC >= 16) v = min(v, dpp_all<DPP_MIRROR>(v));
     return v;
 }
 
@@ -112,13 +113,17 @@ __device__ __forceinline__ void cost_from_operands(u32 cl, const uint4& rb, u32 
 
 // One step of one path for one pixel: consumes the predecessor's normalised state N, produces
 // L' (returned in L) and leaves the new normalised state in N.
-template <bool TAIL>
-__device__ __forceinline__ void sgm_step(u32 (&N)[NR], const u32 (&C)[NR], u32 P1P1, u32 P2P2, const u32 (&tail)[NR], u32 (&L)[NR])
+template <bool TAIL, int LPC = 16>
+__device__ __forceinline__ void sgm_step(u32 (&N)[NR], const u32 (&C)[NR], u32 P1P1, u32 P2P2, const u32 (&tail)[NR], u32 (&L)[NR], int lic = 0)
 {
     // d-1 of this lane's first disparity lives in the previous lane's last B register (high half),
     // d+1 of its last disparity in the next lane's first A register (low half)
-    const u32 prevB = dpp_keep<DPP_ROW_SHR1>(INF2, N[NR - 1]);
-    const u32 nextA = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
+    u32 prevB = dpp_keep<DPP_ROW_SHR1>(INF2, N[NR - 1]);
+    u32 nextA = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
+    if (LPC < 16) {   // several pixels share a DPP row: cut the shifts at the pixel's first / last lane
+        prevB = lic == 0 ? INF2 : prevB;
+        nextA = lic == LPC - 1 ? INF2 : nextA;
+    }
     u32 mn = 0xFFFFFFFFu;
     u32 O[NR];   // predecessor state (N is overwritten group by group below)
 #pragma unroll
@@ -138,7 +143,7 @@ __device__ __forceinline__ void sgm_step(u32 (&N)[NR], const u32 (&C)[NR], u32 P
         mn = g == 0 ? pkmin(LA, LB) : pkmin(mn, pkmin(LA, LB));
     }
     u32 m1 = min(mn & 0xFFFFu, mn >> 16);
-    m1 = row_min16(m1);
+    m1 = row_min16<LPC>(m1);
     const u32 mm = m1 | (m1 << 16);
 #pragma unroll
     for (int r = 0; r < NR; r++) N[r] = pksub(N[r], mm);
@@ -206,9 +211,9 @@ __device__ __forceinline__ void unpack_bytes(const uint4& w, u32 (&L)[NR])
 
 // Winner-take-all on the 16 aggregated costs each lane of a lane-row holds (register order): first
 // minimum over d, the smallest cost outside {best-1, best, best+1} for the uniqueness test, and the
-// two neighbours of the minimum for the parabola fit (through `srow`, this lane-row's 128 dwords
-// of LDS).  Lane 0 of the lane-row writes the record.
-template <bool TAIL>
+// two neighbours of the minimum for the parabola fit (through `srow`, this pixel's LPC*8 dwords
+// of LDS).  The pixel's first lane writes the record.
+template <bool TAIL, int LPC = 16>
 __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[NR], const u32 (&tail)[NR], int lic, u32* srow,
                                           const u32 (*exclMask)[NR], size_t recIndex)
 {
@@ -223,7 +228,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
     }
     const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
     u32 key = ((kl >> 4) << 16) | (u32)(lic * DPL) | (kl & 15u);
-    key = row_min16(key);
+    key = row_min16<LPC>(key);
     const int best = (int)(key & 0xFFFFu);
     const int minS = (int)(key >> 16);
     // smallest S outside {best-1, best, best+1}
@@ -239,7 +244,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
         if (TAIL) v |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
         smin = q == 0 ? v : pkmin(smin, v);
     }
-    const int mex = (int)row_min16(min(smin & 0xFFFFu, smin >> 16));
+    const int mex = (int)row_min16<LPC>(min(smin & 0xFFFFu, smin >> 16));
     // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
     const bool notUnique = mex != 0xFFFF && (mex - a.bias) * (100 - a.uniq) < (minS - a.bias) * 100;
     {
@@ -248,7 +253,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
         dst[1] = make_uint4(Sacc[4], Sacc[5], Sacc[6], Sacc[7]);
     }
     auto s_at = [&](int d) -> u32 {
-        d = min(max(d, 0), 255);
+        d = min(max(d, 0), LPC * DPL - 1);
         const int e = d & 15;
         const int reg = 2 * (e >> 2) + (e & 1), half = (e >> 1) & 1;
         return (srow[(d >> 4) * 8 + reg] >> (16 * half)) & 0xFFFFu;
@@ -278,21 +283,23 @@ __device__ __forceinline__ void init_excl_mask(u32 (*exclMask)[NR])
 }
 
 // ---------------------------------------------------------------------------------------------
-// Horizontal paths: one lane-row per (row, direction), 16 per workgroup; line id < H: (1,0), else (-1,0).
-template <bool TAIL, bool U8>
+// Horizontal paths: LPC lanes per (row, direction), 256/LPC lines per workgroup; line id < H: (1,0), else (-1,0).
+// A pixel occupies LPC*16 disparity slots in every volume (64, 128 or 256).
+template <bool TAIL, bool U8, int LPC>
 __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
 {
-    const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
+    constexpr int DP = LPC * DPL, LINES = 256 / LPC;
+    const int lic = threadIdx.x % LPC, lr = threadIdx.x / LPC;
     const int pair = blockIdx.y;
     const int H = a.H, W = a.W;
-    const int line = blockIdx.x * 16 + lr;
+    const int line = blockIdx.x * LINES + lr;
     if (line >= 2 * H) return;
     const int dir = line >= H, y = line - dir * H;
     const int dx = dir ? -1 : 1;
     int x = dir ? W - 1 : 0;
     const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
     const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR;
-    u8* hrow = a.Hvol[dir] + (size_t)pair * a.strideH + (size_t)y * W * (U8 ? 256 : 512) + lic * (U8 ? 16 : 32);
+    u8* hrow = a.Hvol[dir] + (size_t)pair * a.strideH + (size_t)y * W * (U8 ? DP : 2 * DP) + lic * (U8 ? 16 : 32);
     u32 tail[NR];
     make_tail(lic, a.D, tail);
     u32 N[NR];
@@ -307,9 +314,9 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
         u32 C[NR], L[NR];
         cost_from_operands(cl, rb, C);
         if (t + 1 < W) load_cost_operands(a, cLrow, cRrow, x + dx, lic, cl, rb);
-        sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
-        if (U8) store16_stream(hrow + (size_t)x * 256, pack_bytes(L));
-        else store8(reinterpret_cast<u16*>(hrow + (size_t)x * 512), L);
+        sgm_step<TAIL, LPC>(N, C, a.P1P1, a.P2P2, tail, L, lic);
+        if (U8) store16_stream(hrow + (size_t)x * DP, pack_bytes(L));
+        else store8(reinterpret_cast<u16*>(hrow + (size_t)x * 2 * DP), L);
         x += dx;
     }
 }
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 
 // ---------------------------------------------------------------------------------------------
 // Sheared sweep (byte-state mode only): the same three paths per sweep as sgm2_sweep_kernel, but a
-// workgroup owns 16 columns of the SHEARED frame c = x - y.  In that frame
+// workgroup owns 256/LPC columns of the SHEARED frame c = x - y.  In that frame
 //   down sweep:  (1,1)  stays in its column (registers),  (0,1) arrives from c+1,  (-1,1) from c+2
 //   up sweep:    (-1,-1) stays in its column,             (0,-1) arrives from c-1, (1,-1) from c-2
 // so every cross-strip dependency points the same way and neighbouring strips form a pipeline:
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 // timeout the error word is set, all waits stop and the host reports the failure.
 struct ShearArgs {
     Sgm2Args a;
-    u8* hand;               // [B][H][nsh][3][256]: per row and strip, V of m=0, B of m=0, B of m=1
+    u8* hand;               // [B][H][nsh][3][LPC*16]: per row and strip, V of m=0, B of m=0, B of m=1
     size_t strideHand;      // bytes per pair
     int* sync;              // [0] ticket (down) [1] ticket (up) [2] error, [16 + (sweep*B + pair)*nsh + k] progress
     int nsh, cmin, batch;
@@ -563,14 +570,16 @@ __device__ __forceinline__ uint4 hand_load(const u8* p)
     return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
-template <bool UP, bool TAIL, bool FUSE, bool S4B>
+template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC>
 __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
 {
+    // LPC lanes share a pixel (16 disparities each); a strip is CW = 256/LPC sheared columns wide
+    constexpr int CW = 256 / LPC, DP = LPC * DPL, SW = LPC * 4;
     const Sgm2Args& a = sa.a;
-    __shared__ u32 vs[2][CW][64];      // vertical-path states of the previous / current row, as bytes
-    __shared__ u32 bs[2][CW][64];      // states of the diagonal that crosses two sheared columns per row
-    __shared__ u32 hin[2][3][64];      // neighbour strip's states for the current / next row: V->m15, B->m14, B->m15
-    __shared__ u32 srow[FUSE ? CW : 1][FUSE ? 128 : 1];
+    __shared__ u32 vs[2][CW][SW];      // vertical-path states of the previous / current row, as bytes
+    __shared__ u32 bs[2][CW][SW];      // states of the diagonal that crosses two sheared columns per row
+    __shared__ u32 hin[2][3][SW];      // neighbour strip's states for the current / next row: V->m=CW-1, B->m=CW-2, B->m=CW-1
+    __shared__ u32 srow[FUSE ? CW : 1][FUSE ? LPC * 8 : 1];
     __shared__ u32 exclMask[FUSE ? 19 : 1][NR];
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = atomicAdd(&sa.sync[UP ? 1 : 0], 1);
@@ -590,19 +599,19 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     const bool hasNb = nbk >= 0 && nbk < sa.nsh;
     auto has_prev = [&](int y) { return UP ? y < H - 1 : y > 0; };
     auto hand_slot = [&](int y, int strip, int which, int lic) -> u8* {
-        return hand + ((((size_t)y * sa.nsh + strip) * 3 + which) * 256 + lic * 16);
+        return hand + ((((size_t)y * sa.nsh + strip) * 3 + which) * DP + lic * 16);
     };
 
     if (threadIdx.x >= 256) {
         // ---- communication wave: publishes this strip's edge states one row behind the compute
         // waves and fetches the neighbour's one row ahead of them, so that neither the write-through
         // drain nor a wait for a slow neighbour sits in the compute waves' instruction stream
-        const int lane = threadIdx.x - 256, which = lane >> 4, lic = lane & 15;
+        const int lane = threadIdx.x - 256, which = lane / LPC, lic = lane % LPC;
         int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
         const int* progNb = progMe + (UP ? -1 : 1);
         int* errWord = sa.sync + 2;
         int seen = 0;
-        // m = 15 sits in sheared column c0 + 15 (down) / c0 (up); m = 14 next to it
+        // m = CW-1 sits in sheared column c0 + CW-1 (down) / c0 (up); m = CW-2 next to it
         const int c15 = UP ? c0 : c0 + CW - 1, c14 = UP ? c0 + 1 : c0 + CW - 2;
         // does this lane fetch a neighbour state for row i?
         auto wants = [&](int i) -> bool {
@@ -677,8 +686,8 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     }
 
     // ---- compute waves ----
-    const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
-    const int m = UP ? 15 - lr : lr;                          // column index counted against the dependency direction
+    const int lic = threadIdx.x % LPC, lr = threadIdx.x / LPC;
+    const int m = UP ? CW - 1 - lr : lr;                          // column index counted against the dependency direction
     const int c = c0 + lr;
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
@@ -705,16 +714,16 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     const bool five = !UP && a.five;   // this down sweep also adds the (-1,0) volume and finishes the sum
     const u8* Hp2 = a.Hvol[1] + (size_t)pair * a.strideH;
     uint4 sb = make_uint4(0, 0, 0, 0);
-    // S4B: the four-path partial sum fits a byte per disparity and travels as 256 bytes per pixel
+    // S4B: the four-path partial sum fits a byte per disparity and travels as one byte per slot
     u8* Sb = reinterpret_cast<u8*>(Sp);
     auto fetch_row = [&](int i) {
         const int y = ys + sy * i, x = c + y;
         if (x >= 0 && x < W) {
             load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
             const size_t pix = (size_t)y * W + x;
-            hb = load16_stream(Hp + pix * 256 + lic * 16);
-            if (five) hb2 = load16_stream(Hp2 + pix * 256 + lic * 16);
-            if (UP) { if (S4B) sb = load16_stream(Sb + pix * 256 + lic * 16); else load8_stream(Sp + (pix * 256 + lic * DPL), Snext); }
+            hb = load16_stream(Hp + pix * DP + lic * 16);
+            if (five) hb2 = load16_stream(Hp2 + pix * DP + lic * 16);
+            if (UP) { if (S4B) sb = load16_stream(Sb + pix * DP + lic * 16); else load8_stream(Sp + (pix * DP + lic * DPL), Snext); }
         }
     };
     fetch_row(0);
@@ -743,28 +752,28 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         if (active) {
             // diagonal resident in this column: predecessor (x-1, y-1) going down, (x+1, y+1) going up
             if (!hasPrev || (UP ? x == W - 1 : x == 0)) fresh(Nr);
-            sgm_step<TAIL>(Nr, C, P1P1, P2P2, tail, L);
+            sgm_step<TAIL, LPC>(Nr, C, P1P1, P2P2, tail, L, lic);
 #pragma unroll
             for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             // vertical path: predecessor (x, y -+ 1) lives one sheared column further
             u32 N[NR];
             if (!hasPrev) fresh(N);
-            else if (m < 15) from_bytes(*reinterpret_cast<const uint4*>(&vs[par ^ 1][m + 1][lic * 4]), N);
+            else if (m < CW - 1) from_bytes(*reinterpret_cast<const uint4*>(&vs[par ^ 1][m + 1][lic * 4]), N);
             else from_bytes(*reinterpret_cast<const uint4*>(&hin[par][0][lic * 4]), N);
-            sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
 #pragma unroll
             for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             *reinterpret_cast<uint4*>(&vs[par][m][lic * 4]) = pack_bytes(N);
             // the other diagonal: predecessor (x+1, y-1) going down, (x-1, y+1) going up, two columns further
             if (!hasPrev || (UP ? x == 0 : x == W - 1)) fresh(N);
-            else if (m < 14) from_bytes(*reinterpret_cast<const uint4*>(&bs[par ^ 1][m + 2][lic * 4]), N);
-            else from_bytes(*reinterpret_cast<const uint4*>(&hin[par][m - 13][lic * 4]), N);
-            sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+            else if (m < CW - 2) from_bytes(*reinterpret_cast<const uint4*>(&bs[par ^ 1][m + 2][lic * 4]), N);
+            else from_bytes(*reinterpret_cast<const uint4*>(&hin[par][m - (CW - 3)][lic * 4]), N);
+            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
 #pragma unroll
             for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             *reinterpret_cast<uint4*>(&bs[par][m][lic * 4]) = pack_bytes(N);
             const size_t pix = (size_t)y * W + x;
-            if (FUSE) fused_wta<TAIL>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
+            if (FUSE) fused_wta<TAIL, LPC>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
             else if ((UP || five) && a.naturalOut) {
                 u32 nat[NR];
 #pragma unroll
@@ -772,9 +781,9 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                     nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
                     nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
-                store8(Sp + (pix * 256 + lic * DPL), nat);
-            } else if (S4B) store16_stream(Sb + pix * 256 + lic * 16, pack_bytes(Sacc));
-            else store8_stream(Sp + (pix * 256 + lic * DPL), Sacc);
+                store8(Sp + (pix * DP + lic * DPL), nat);
+            } else if (S4B) store16_stream(Sb + pix * DP + lic * 16, pack_bytes(Sacc));
+            else store8_stream(Sp + (pix * DP + lic * DPL), Sacc);
         }
         __syncthreads();   // vs/bs[par] complete before the next row reads them
     }
@@ -841,20 +850,42 @@ __global__ __launch_bounds__(256) void sgm2_lr_kernel(LrArgs a)
 
 static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin + pl.P2 <= 255; }
 
-static int shear_strips(int H, int W) { return (W + H - 1 + CW - 1) / CW; }
-static size_t shear_hand_bytes(int H, int W) { return md_align((size_t)H * shear_strips(H, W) * 3 * 256, 256); }
-static size_t shear_sync_bytes(int H, int W, int batch) { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W)) * sizeof(int), 256); }
 // the pipelined sheared sweeps replace the border pre-pass whenever path values fit a byte
 static bool use_shear(bool u8mode) { return u8mode && !getenv("MDISP_SGM_PREPASS"); }
 
-size_t md_sgm2_extra_bytes(int H, int W, int batch, int u8mode)
+// lanes per pixel: the sheared kernels run 64 / 128 / 256 disparity slots per pixel, the others always 256
+static int lanes_per_pixel(const md_sgm_plan& pl)
 {
-    const int nstrips = (W + CW - 1) / CW;
-    size_t bnd = md_align((size_t)H * nstrips * 256 * sizeof(u16), 256) * 4;
-    if (u8mode && shear_hand_bytes(H, W) > bnd) bnd = shear_hand_bytes(H, W);
-    const size_t hvol = md_align((size_t)H * W * 256 * (u8mode ? 1 : 2), 256) * 2;
-    const size_t rec = md_align((size_t)H * W * sizeof(uint2), 256);
-    return (bnd + hvol + rec) * batch + shear_sync_bytes(H, W, batch);
+    if (!use_shear(fits_u8(pl)) || getenv("MDISP_SGM_LANES16")) return 16;
+    return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
+}
+int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
+
+static int shear_strips(int H, int W, int cw) { return (W + H - 1 + cw - 1) / cw; }
+static size_t shear_hand_bytes(int H, int W, int lpc) { return md_align((size_t)H * shear_strips(H, W, 256 / lpc) * 3 * lpc * DPL, 256); }
+static size_t shear_sync_bytes(int H, int W, int batch, int lpc)
+{ return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, 256 / lpc)) * sizeof(int), 256); }
+
+struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, syncBytes; int nstrips, lpc, slots; bool u8m; };
+static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
+{
+    Sgm2Layout l;
+    l.u8m = fits_u8(pl);
+    l.lpc = lanes_per_pixel(pl);
+    l.slots = l.lpc * DPL;
+    l.nstrips = (pl.W + CW - 1) / CW;
+    if (use_shear(l.u8m)) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc); }   // hand-off rows
+    else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
+    l.oneH = md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
+    l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
+    l.syncBytes = shear_sync_bytes(pl.H, pl.W, batch, l.lpc);
+    return l;
+}
+
+size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
+{
+    const Sgm2Layout l = sgm2_layout(pl, batch);
+    return (l.bndBytes + 2 * l.oneH + l.oneRec) * batch + l.syncBytes;
 }
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
@@ -865,7 +896,36 @@ bool md_sgm2_supported(const md_sgm_plan& pl)
 
 bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
 
-// S must hold H*W*256 u16 per pair; extra md_sgm2_extra_bytes() bytes
+namespace {
+template <int LPC>
+int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int batch, int naturalOut)
+{
+    const Sgm2Args& a = sa.a;
+    constexpr int LINES = 256 / LPC;
+    dim3 gh((2 * pl.H + LINES - 1) / LINES, batch), gs((unsigned)sa.nsh * batch);
+#define SGM2_SHEAR(TAILV, S4BV)                                                                           \
+    do {                                                                                                  \
+        sgm2_hscan_kernel<TAILV, true, LPC><<<gh, 256, 0, s>>>(a);                                        \
+        sgm2_shear_kernel<false, TAILV, false, S4BV, LPC><<<gs, 320, 0, s>>>(sa);                         \
+        if (naturalOut) sgm2_shear_kernel<true, TAILV, false, S4BV, LPC><<<gs, 320, 0, s>>>(sa);          \
+        else sgm2_shear_kernel<true, TAILV, true, S4BV, LPC><<<gs, 320, 0, s>>>(sa);                      \
+    } while (0)
+    // the down sweep's four-path sum stays below 256 for small P2: half the volume traffic
+    const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+    if (a.five) {
+        // -> and <- from the horizontal scan, the three downward paths and the winner-take-all in ONE sweep
+        sgm2_hscan_kernel<true, true, LPC><<<gh, 256, 0, s>>>(a);
+        if (naturalOut) sgm2_shear_kernel<false, true, false, false, LPC><<<gs, 320, 0, s>>>(sa);
+        else sgm2_shear_kernel<false, true, true, false, LPC><<<gs, 320, 0, s>>>(sa);
+    } else if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
+    else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
+#undef SGM2_SHEAR
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+}  // namespace
+
+// S must hold H*W*md_sgm2_slots() u16 per pair; extra md_sgm2_extra_bytes() bytes
 // naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
 // naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
@@ -873,62 +933,42 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
 {
     Sgm2Args a;
     if (errWord) *errWord = nullptr;
+    const Sgm2Layout l = sgm2_layout(pl, batch);
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
     a.cR = cR; a.pR = pl.pitchR; a.strideR = strideR;
     a.S = S; a.strideS = strideS;
     a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD;
-    a.nstrips = (pl.W + CW - 1) / CW;
-    const bool u8m = fits_u8(pl);
-    const size_t oneB = md_align((size_t)pl.H * a.nstrips * 256 * sizeof(u16), 256);
-    size_t bndBytes = 4 * oneB;                       // per pair: four border-state planes, or the hand-off rows
-    if (u8m && shear_hand_bytes(pl.H, pl.W) > bndBytes) bndBytes = shear_hand_bytes(pl.H, pl.W);
-    for (int i = 0; i < 4; i++) a.bnd[i] = (u16*)(extra + (size_t)i * oneB * batch);
-    a.strideB = oneB / sizeof(u16);
-    const size_t oneH = md_align((size_t)pl.H * pl.W * 256 * (u8m ? 1 : 2), 256);
-    u8* hbase = extra + bndBytes * batch;
-    a.Hvol[0] = hbase; a.Hvol[1] = hbase + oneH * batch;
-    a.strideH = oneH;
+    a.nstrips = l.nstrips;
+    const bool u8m = l.u8m;
+    for (int i = 0; i < 4; i++) a.bnd[i] = (u16*)(extra + (size_t)i * l.oneB * batch);
+    a.strideB = l.oneB / sizeof(u16);
+    u8* hbase = extra + l.bndBytes * batch;
+    a.Hvol[0] = hbase; a.Hvol[1] = hbase + l.oneH * batch;
+    a.strideH = l.oneH;
     a.P1P1 = (u32)pl.P1 | ((u32)pl.P1 << 16);
     a.P2P2 = (u32)pl.P2 | ((u32)pl.P2 << 16);
-    a.tail = pl.D < 256;
+    a.tail = pl.D < l.slots;
     a.naturalOut = naturalOut;
     a.five = pl.npaths == 5;
-    const size_t oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
-    a.rec = (uint2*)(hbase + 2 * oneH * batch);
-    a.strideRec = oneRec / sizeof(uint2);
+    a.rec = (uint2*)(hbase + 2 * l.oneH * batch);
+    a.strideRec = l.oneRec / sizeof(uint2);
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
     if (use_shear(u8m)) {
         ShearArgs sa;
         sa.a = a;
-        sa.hand = extra; sa.strideHand = bndBytes;
-        sa.sync = (int*)(hbase + 2 * oneH * batch + oneRec * batch);
-        sa.nsh = shear_strips(pl.H, pl.W); sa.cmin = -(pl.H - 1); sa.batch = batch;
-        MD_HIP(hipMemsetAsync(sa.sync, 0, shear_sync_bytes(pl.H, pl.W, batch), s));
+        sa.hand = extra; sa.strideHand = l.bndBytes;
+        sa.sync = (int*)(hbase + 2 * l.oneH * batch + l.oneRec * batch);
+        sa.nsh = shear_strips(pl.H, pl.W, 256 / l.lpc); sa.cmin = -(pl.H - 1); sa.batch = batch;
+        MD_HIP(hipMemsetAsync(sa.sync, 0, l.syncBytes, s));
         if (errWord) *errWord = sa.sync + 2;
-        dim3 gh((2 * pl.H + 15) / 16, batch), gs((unsigned)sa.nsh * batch);
-#define SGM2_SHEAR(TAILV, S4BV)                                                                      \
-        do {                                                                                         \
-            sgm2_hscan_kernel<TAILV, true><<<gh, 256, 0, s>>>(a);                                    \
-            sgm2_shear_kernel<false, TAILV, false, S4BV><<<gs, 320, 0, s>>>(sa);                     \
-            if (naturalOut) sgm2_shear_kernel<true, TAILV, false, S4BV><<<gs, 320, 0, s>>>(sa);      \
-            else sgm2_shear_kernel<true, TAILV, true, S4BV><<<gs, 320, 0, s>>>(sa);                  \
-        } while (0)
-        // the down sweep's four-path sum stays below 256 for small P2: half the volume traffic
-        const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-        if (a.five) {
-            // -> and <- from the horizontal scan, the three downward paths and the winner-take-all in ONE sweep
-            sgm2_hscan_kernel<true, true><<<gh, 256, 0, s>>>(a);
-            if (naturalOut) sgm2_shear_kernel<false, true, false, false><<<gs, 320, 0, s>>>(sa);
-            else sgm2_shear_kernel<false, true, true, false><<<gs, 320, 0, s>>>(sa);
-        } else if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
-        else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
-#undef SGM2_SHEAR
-        MD_HIP(hipGetLastError());
+        if (l.lpc == 4) MD_TRY(launch_shear<4>(s, pl, sa, batch, naturalOut));
+        else if (l.lpc == 8) MD_TRY(launch_shear<8>(s, pl, sa, batch, naturalOut));
+        else MD_TRY(launch_shear<16>(s, pl, sa, batch, naturalOut));
     } else {
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
     do {                                                                 \
-        sgm2_hscan_kernel<TAILV, U8V><<<gh, 256, 0, s>>>(a);             \
+        sgm2_hscan_kernel<TAILV, U8V, 16><<<gh, 256, 0, s>>>(a);         \
         sgm2_prepass_kernel<TAILV><<<gp, 256, 0, s>>>(a);                \
         sgm2_sweep_kernel<false, TAILV, U8V, false><<<gs, 256, 0, s>>>(a);                           \
         if (naturalOut) sgm2_sweep_kernel<true, TAILV, U8V, false><<<gs, 256, 0, s>>>(a);            \
@@ -940,10 +980,10 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     MD_HIP(hipGetLastError());
     }
     if (!naturalOut) {
-        LrArgs l;
-        l.rec = a.rec; l.strideRec = a.strideRec; l.H = pl.H; l.W = pl.W; l.D = pl.D; l.minD = pl.minD;
-        l.maxDiff = pl.maxDiff; l.subpixel = pl.subpixel; l.disp = dDisp; l.strideDisp = (size_t)pl.H * pl.W;
-        sgm2_lr_kernel<<<dim3(pl.H, batch), 256, (size_t)pl.W * 6 + 16, s>>>(l);
+        LrArgs l2;
+        l2.rec = a.rec; l2.strideRec = a.strideRec; l2.H = pl.H; l2.W = pl.W; l2.D = pl.D; l2.minD = pl.minD;
+        l2.maxDiff = pl.maxDiff; l2.subpixel = pl.subpixel; l2.disp = dDisp; l2.strideDisp = (size_t)pl.H * pl.W;
+        sgm2_lr_kernel<<<dim3(pl.H, batch), 256, (size_t)pl.W * 6 + 16, s>>>(l2);
         MD_HIP(hipGetLastError());
     }
     return MDISP_OK;

@@ -152,6 +152,10 @@ SGM_CASES = [
     (60, 300, 0, 256, 8, 32, 10, 1, 5, 1),      # five paths (StereoSGBM's default mode): one fused down sweep
     (75, 40, 1, 20, 2, 5, 10, 1, 5, 0),
     (50, 80, 0, 64, 20, 300, 10, 1, 5, 1),      # five paths with 16-bit path values: per-direction fallback
+    (120, 260, 0, 64, 8, 32, 10, 1, 8, 1),      # four lanes per pixel, several 64-column strips
+    (90, 200, 1, 65, 8, 32, 10, 1, 8, 1),       # just above the four-lane limit: eight lanes, masked tail
+    (100, 330, 0, 96, 6, 60, 10, 2, 8, 1),      # eight lanes per pixel, 16-bit four-path sums
+    (80, 150, 0, 40, 8, 32, 10, 1, 5, 1),       # four lanes per pixel, five paths
 ]
 
 
