@@ -19,7 +19,7 @@ BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCA
 # aggregation of the Hamming slices in censusStereo
 AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
 # GIF_TYPE, gifs.h:4-13
-GIF, WGIF, EGIF, SKWGIF = range(4)
+GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 = range(7)
 COST_VOLUME, COST_CENSUS, COST_ABSDIFF = range(3)
 # StereoMatchingAlgorithms, methods/parametersStereo.h (only the entry built here)
 SGBM = 1
@@ -163,6 +163,21 @@ def getGuidedFilter_egif(guidedImg, inputP, r, eps, ctx=None):
 def getGuidedFilter_skwgif2(guidedImg, inputP, steerFilterW, r, r2, eps, namuda, h=0.5, ctx=None):
     """gifs.h:33 (`h` is accepted and, as in the reference, unused)."""
     return _guided(guidedImg, inputP, r, eps, SKWGIF, steerFilterW, r2, namuda, False, ctx)
+
+
+def getGuidedFilter_ours_gif(guidedImg, inputP, r, r2, eps, namuda, h=0.5, ctx=None):
+    """gifs.h:36: WGIF-like coefficients (gamma from the r2-window variance), bilateral-smoothed."""
+    return _guided(guidedImg, inputP, r, eps, OURS_GIF, None, r2, namuda, False, ctx)
+
+
+def getGuidedFilter_ours_gif2(guidedImg, inputP, r, r2, eps, namuda, h=0.5, ctx=None):
+    """gifs.h:37: plain guided-filter coefficients, bilateral-smoothed."""
+    return _guided(guidedImg, inputP, r, eps, OURS_GIF2, None, r2, namuda, False, ctx)
+
+
+def getGuidedFilter_ours_gif3(guidedImg, inputP, r, r2, eps, namuda, h=0.5, ctx=None):
+    """gifs.h:38: EGIF coefficients, bilateral-smoothed with diameter r -> (filtered, beta)."""
+    return _guided(guidedImg, inputP, r, eps, OURS_GIF3, None, r2, namuda, True, ctx)
 
 
 def steerFilter(src, ctx=None):

@@ -445,8 +445,7 @@ extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
     int rc;
     if ((rc = check_pair(L, R, p))) return rc;
     if ((rc = check_out(out, L->rows, L->cols, MDISP_32F, 1, "out"))) return rc;
-    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_SKWGIF, MDISP_E_UNSUPPORTED,
-               "GIF type %d is not built (OURS_GIF* need the bilateral stage)", gif_type);
+    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_OURS_GIF3, MDISP_E_BADARG, "unknown GIF type %d", gif_type);
     MD_REQUIRE(cost_source != MDISP_COST_VOLUME || costs, MDISP_E_BADARG, "cost volume source needs the slices");
     MD_HIP(hipSetDevice(c->device));
     const int H = L->rows, W = L->cols, maxD = p->maxDisparity, minD = p->minDisparity, D = maxD - minD + 1, Wp = W + maxD;
@@ -488,8 +487,7 @@ extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0 && p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity,
                MDISP_E_BADARG, "bad function parameters, please check image and window size.");
     MD_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= rows, MDISP_E_BADARG, "bad row band [%d, %d)", row_begin, row_end);
-    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_SKWGIF, MDISP_E_UNSUPPORTED,
-               "GIF type %d is not built (OURS_GIF* need the bilateral stage)", gif_type);
+    MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_OURS_GIF3, MDISP_E_BADARG, "unknown GIF type %d", gif_type);
     MD_REQUIRE(cost_source == MDISP_COST_CENSUS || cost_source == MDISP_COST_ABSDIFF, MDISP_E_BADARG,
                "the band entry point forms its cost slices on the device (census or absdiff)");
     if (row_begin == row_end) return MDISP_OK;

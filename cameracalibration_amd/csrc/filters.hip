@@ -667,6 +667,64 @@ static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode,
 }
 
 // ---------------------------------------------------------------------------------------------
+// bilateralFilter(a), bilateralFilter(b) of the coefficient planes (gifs.cpp:661-662, 717-718,
+// 785-786: sigmaColor 2, sigmaSpace 3) fused with the final a*G + b (:667, 723, 802) and the
+// optional beta = a/(1-a) (:792).  Footprint = the taps within `radius` of the centre, visited in
+// row-major order with float accumulation like the library's scalar loop; BORDER_REFLECT_101.
+// The library interpolates the colour weight from a 4096-bin table of exp(); this kernel
+// evaluates the exponential directly (difference below 1e-6 of the weight).
+#define BIL_X 32
+#define BIL_Y 16
+struct BilArgs {
+    const float* A; const float* B; size_t N;
+    int H, W, R, ntaps, yA, yB;
+    const int2* taps;        // {offset in the (a,b) tile, bits of the float space weight}
+    const float* G; float* V; float* beta;
+    float colorK;            // -0.5/sigmaColor^2 * log2(e)
+};
+__global__ __launch_bounds__(256) void bilateral_ab_kernel(BilArgs a)
+{
+    extern __shared__ float2 biltile[];
+    const int R = a.R, TW = BIL_X + 2 * R, TH = BIL_Y + 2 * R;
+    const int x0 = blockIdx.x * BIL_X, y0 = a.yA + blockIdx.y * BIL_Y, k = blockIdx.z;
+    const float* A = a.A + (size_t)k * a.N;
+    const float* B = a.B + (size_t)k * a.N;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int ty = i / TW, tx = i - ty * TW;
+        const size_t src = (size_t)r101(y0 + ty - R, a.H) * a.W + r101(x0 + tx - R, a.W);
+        biltile[i] = make_float2(A[src], B[src]);
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // pixels (tx, ty) and (tx, ty + 8) of the tile
+    const int c0 = (ty + R) * TW + tx + R, c1 = c0 + 8 * TW;
+    const float2 v0 = biltile[c0], v1 = biltile[c1];
+    float sa0 = 0, wa0 = 0, sb0 = 0, wb0 = 0, sa1 = 0, wa1 = 0, sb1 = 0, wb1 = 0;
+    const float K = a.colorK;
+    for (int t = 0; t < a.ntaps; t++) {
+        const int2 tp = a.taps[t];
+        const float ws = __int_as_float(tp.y);
+        const float2 p = biltile[c0 + tp.x], q = biltile[c1 + tp.x];
+        float d, w;
+        d = p.x - v0.x; w = ws * __builtin_amdgcn_exp2f(d * d * K); sa0 += __fmul_rn(p.x, w); wa0 += w;
+        d = p.y - v0.y; w = ws * __builtin_amdgcn_exp2f(d * d * K); sb0 += __fmul_rn(p.y, w); wb0 += w;
+        d = q.x - v1.x; w = ws * __builtin_amdgcn_exp2f(d * d * K); sa1 += __fmul_rn(q.x, w); wa1 += w;
+        d = q.y - v1.y; w = ws * __builtin_amdgcn_exp2f(d * d * K); sb1 += __fmul_rn(q.y, w); wb1 += w;
+    }
+    const int x = x0 + tx;
+    if (x >= a.W) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int y = y0 + ty + 8 * h;
+        if (y >= a.yB) break;
+        const float ab = h ? __fdiv_rn(sa1, wa1) : __fdiv_rn(sa0, wa0);
+        const float bb = h ? __fdiv_rn(sb1, wb1) : __fdiv_rn(sb0, wb0);
+        const size_t i = (size_t)y * a.W + x, o = (size_t)k * a.N + i;
+        a.V[o] = __fadd_rn(__fmul_rn(ab, a.G[i]), bb);
+        if (a.beta) a.beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // steerable-filter orientation strength (steerFilter.cpp:239-446)
 
 struct SteerTaps { double k[7][121]; };   // G2a, G2b, H2a, H2b, G2c, H2c, H2d sampled at integer taps
@@ -814,7 +872,16 @@ struct GuideState {
     float* den;      // var + regulariser
     float* w;        // steer weights as float (SKWGIF)
     double* wsum;    // clipped-window sum of w (SKWGIF)
+    int2* bilTaps; int bilR, bilN;   // OURS_GIF*: footprint of the bilateral stage (radius, tap count)
 };
+static bool is_ours(int type) { return type == MDISP_OURS_GIF || type == MDISP_OURS_GIF2 || type == MDISP_OURS_GIF3; }
+// diameter cv::bilateralFilter receives (gifs.cpp:661, 717: r2; :785: r) -> radius
+static int ours_radius(int type, int r, int r2)
+{
+    const int d = type == MDISP_OURS_GIF3 ? r : r2;
+    const int radius = d <= 0 ? 4 /* cvRound(3 * 1.5) */ : d / 2;
+    return radius < 1 ? 1 : radius;
+}
 
 struct GifScratch {   // device scratch sized for n slices
     size_t N; int n;
@@ -868,14 +935,35 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
     if ((rc = box_f32(s, gs.G, 0, gs.G, 0, 1, H, W, r, 0, sc.gd, nullptr, sc.g0))) return rc;
     var_kernel<<<nblk(N), 256, 0, s>>>(sc.g0, gs.meanG, N, sc.g1);   // g1 = varG
     const float epsf = (float)eps;
-    if (type == MDISP_GIF) {
+    gs.bilTaps = nullptr; gs.bilR = 0; gs.bilN = 0;
+    // regulariser of the coefficient stage: OURS_GIF as SKWGIF (gifs.cpp:646-652), OURS_GIF2 as GIF (:706),
+    // OURS_GIF3 as EGIF (:753-754)
+    const int denType = type == MDISP_OURS_GIF ? MDISP_SKWGIF : type == MDISP_OURS_GIF2 ? MDISP_GIF : type == MDISP_OURS_GIF3 ? MDISP_EGIF : type;
+    if (is_ours(type)) {
+        const int R = ours_radius(type, r, r2), TW = BIL_X + 2 * R;
+        std::vector<int2> taps;
+        const double gsc = -0.5 / (3.0 * 3.0);
+        for (int i = -R; i <= R; i++)
+            for (int j = -R; j <= R; j++) {
+                const double rr = sqrt((double)i * i + (double)j * j);
+                if (rr > R) continue;
+                const float w = (float)exp(rr * rr * gsc);
+                int2 t; t.x = i * TW + j; memcpy(&t.y, &w, 4);
+                taps.push_back(t);
+            }
+        gs.bilR = R; gs.bilN = (int)taps.size();
+        gs.bilTaps = cv.take<int2>(taps.size());
+        MD_HIP(hipMemcpyAsync(gs.bilTaps, taps.data(), taps.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+        MD_HIP(hipStreamSynchronize(s));     // `taps` leaves scope
+    }
+    if (denType == MDISP_GIF) {
         den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, epsf, gs.den);
-    } else if (type == MDISP_EGIF) {
+    } else if (denType == MDISP_EGIF) {
         double sum;
         if ((rc = device_sum(c, sc.g1, N, sc.part, &sum))) return rc;
         const double mean2Var = sum / ((double)W * H);            // gifs.cpp:252
         den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, (float)(mean2Var * eps + 0.001 * 0.001), gs.den);
-    } else if (type == MDISP_WGIF) {
+    } else if (denType == MDISP_WGIF) {
         // edgeAwareWeight (gifs.cpp:347-374): with r = 1 the box "variance" G*G - G*G is exactly 0,
         // so gamma is one constant, evaluated here with the same float operations
         u32 hmm[2];
@@ -895,8 +983,9 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
         const float gamma = gauss3_const(g0v);
         volatile float e = epsf / gamma;
         den_scalar_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, N, e, gs.den);
-    } else if (type == MDISP_SKWGIF) {
-        MD_REQUIRE(steerW_dev && r2 >= 2, MDISP_E_BADARG, "SKWGIF needs the steer-filter weights and r2 >= 2");
+    } else if (denType == MDISP_SKWGIF) {
+        MD_REQUIRE(type != MDISP_SKWGIF || (steerW_dev && r2 >= 2), MDISP_E_BADARG, "SKWGIF needs the steer-filter weights and r2 >= 2");
+        MD_REQUIRE(r2 >= 1, MDISP_E_BADARG, "r2 must be >= 1");
         // var over the r2 window (gifs.cpp:547,555,562)
         if ((rc = box_f32(s, gs.G, 0, nullptr, 0, 1, H, W, r2, 0, sc.gd, nullptr, sc.g2))) return rc;     // meanG2
         if ((rc = box_f32(s, gs.G, 0, gs.G, 0, 1, H, W, r2, 0, sc.gd, nullptr, sc.g0))) return rc;        // corrG2
@@ -907,6 +996,7 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
         if ((rc = device_sum(c, inv, N, sc.part, &sum))) return rc;
         const float gscale = (float)(sum / ((double)H * W));
         skw_den_kernel<<<nblk(N), 256, 0, s>>>(sc.g1, temp, N, gscale, epsf, gs.den);
+        if (type == MDISP_SKWGIF) {
         // steer weights: float copy (gifs.cpp:574-577) and their clipped-window sum (:600)
         gs.w = cv.take<float>(N); gs.wsum = cv.take<double>(N);
         f64_to_f32_kernel<<<nblk(N), 256, 0, s>>>(steerW_dev, N, gs.w);
@@ -916,6 +1006,7 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
         double* hs2 = cv.take<double>(N);
         box_v_f64_kernel<<<gv, 256, 0, s>>>(sc.gd, H, W, r2, 1, hs2);
         gs.wsum = hs2;
+        }
     } else {
         mdisp_set_error("unknown GIF type %d", type);
         return MDISP_E_BADARG;
@@ -939,8 +1030,9 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
         mdisp_set_error("guided-filter window above %d is not supported", MW);
         return MDISP_E_UNSUPPORTED;
     }
+    const bool ours = is_ours(gs.type);
     // output rows [yA, yB): the second filter reads a and b up to one window above and below them
-    const int k2 = skw ? gs.r2 : r;
+    const int k2 = ours ? gs.bilR : skw ? gs.r2 : r;
     const int yA1 = yA - k2 < 0 ? 0 : yA - k2, yB1 = yB + k2 > H ? H : yB + k2;
     // (P, G*P) -> means -> a -> F1, b -> F2   (gifs.cpp:60-61,71,96,127-128)
     StoreAB sab{sc.F1, sc.F2, N, W, gs.meanG, gs.den, 1.0 / ((double)r * r)};
@@ -950,6 +1042,19 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
     } else {
         LoadPlanarGP ld{sc.F0, N, W, gs.G};
         if ((rc = dual_box_march(s, n, H, W, r, 0, yA1, yB1, ld, sab))) return rc;
+    }
+    if (ours) {
+        BilArgs b;
+        b.A = sc.F1; b.B = sc.F2; b.N = N; b.H = H; b.W = W; b.R = gs.bilR; b.ntaps = gs.bilN; b.yA = yA; b.yB = yB;
+        b.taps = gs.bilTaps; b.G = gs.G; b.V = sc.F0; b.beta = beta;
+        b.colorK = (float)(-0.5 / (2.0 * 2.0) * 1.4426950408889634);
+        const size_t lds = (size_t)(BIL_X + 2 * gs.bilR) * (BIL_Y + 2 * gs.bilR) * sizeof(float2);
+        if (lds > 64 * 1024) { mdisp_set_error("bilateral radius %d is not supported", gs.bilR); return MDISP_E_UNSUPPORTED; }
+        if (yB <= yA) return MDISP_OK;
+        dim3 grid((W + BIL_X - 1) / BIL_X, (yB - yA + BIL_Y - 1) / BIL_Y, n);
+        bilateral_ab_kernel<<<grid, 256, lds, s>>>(b);
+        MD_HIP(hipGetLastError());
+        return MDISP_OK;
     }
     // (a, b) -> means -> a_bar*G + b_bar -> F0; SKWGIF: steer-weighted means boxsum(w*a)/boxsum(w)
     // over the clipped r2 window (gifs.cpp:587-611)
@@ -981,7 +1086,7 @@ static int pick_batch(size_t N, int D)
     return (int)n;
 }
 
-static size_t guide_extra_bytes(size_t N) { return md_align(N * 4, 256) * 8 + md_align(N * 8, 256) * 2; }
+static size_t guide_extra_bytes(size_t N) { return md_align(N * 4, 256) * 8 + md_align(N * 8, 256) * 2 + 32768 /* bilateral taps */; }
 
 static int check_img(const mdisp_image* im, const char* what)
 {

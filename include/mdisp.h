@@ -83,12 +83,17 @@ enum {
     MDISP_AGG_GUIDED = 3
 };
 
-/* GIF_TYPE, disp_method/gifs.h:4-13 (same numeric values for the built ones). */
+/* GIF_TYPE, disp_method/gifs.h:4-13 (same numeric values).  OURS_GIF / OURS_GIF2 / OURS_GIF3
+ * (disp_method/gifs.cpp:620-669, 672-725, 728-804) smooth the coefficients a, b with
+ * cv::bilateralFilter(sigmaColor 2, sigmaSpace 3, diameter r2 / r2 / r) instead of a box mean. */
 enum {
     MDISP_GIF = 0,
     MDISP_WGIF = 1,
     MDISP_EGIF = 2,
-    MDISP_SKWGIF = 3
+    MDISP_SKWGIF = 3,
+    MDISP_OURS_GIF = 4,
+    MDISP_OURS_GIF2 = 5,
+    MDISP_OURS_GIF3 = 6
 };
 
 /* cost source of mdisp_asw_gifs */

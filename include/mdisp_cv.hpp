@@ -36,7 +36,7 @@ using mdisp::CENSUS_ALGORITHM;
 using mdisp::BASIC_CENSUS; using mdisp::CIRCLE_CENSUS; using mdisp::ROTATION_INVARIANT_CENSUS; using mdisp::UNIFORM_CENSUS;
 using mdisp::MULTISCALE_CENSUS; using mdisp::STATISTIC_MULTISCALE_CENSUS; using mdisp::CENSUS_2017;
 using mdisp::GIF_TYPE;
-using mdisp::GIF; using mdisp::WGIF; using mdisp::EGIF; using mdisp::SKWGIF;
+using mdisp::GIF; using mdisp::WGIF; using mdisp::EGIF; using mdisp::SKWGIF; using mdisp::OURS_GIF; using mdisp::OURS_GIF2; using mdisp::OURS_GIF3;
 
 // disp_method/methods_disp.h:43-44, 48-55, 61-62, 66
 inline cv::Mat computeSAD_inteOpti(StereoMatchParam param) { return mdisp::computeSAD_inteOpti(param); }
@@ -59,6 +59,13 @@ inline cv::Mat getGuidedFilter_egif(cv::Mat guidedImg, cv::Mat inputP, int r, do
 { return mdisp::getGuidedFilter_egif(guidedImg, inputP, r, eps, beta_); }
 inline cv::Mat getGuidedFilter_skwgif2(cv::Mat guidedImg, cv::Mat inputP, cv::Mat steerFilterW, int r, int r2, double eps, double namuda, double h)
 { return mdisp::getGuidedFilter_skwgif2(guidedImg, inputP, steerFilterW, r, r2, eps, namuda, h); }
+// disp_method/gifs.h:36-38
+inline cv::Mat getGuidedFilter_ours_gif(cv::Mat guidedImg, cv::Mat inputP, int r, int r2, double eps, double namuda, double h)
+{ return mdisp::getGuidedFilter_ours_gif(guidedImg, inputP, r, r2, eps, namuda, h); }
+inline cv::Mat getGuidedFilter_ours_gif2(cv::Mat guidedImg, cv::Mat inputP, int r, int r2, double eps, double namuda, double h)
+{ return mdisp::getGuidedFilter_ours_gif2(guidedImg, inputP, r, r2, eps, namuda, h); }
+inline cv::Mat getGuidedFilter_ours_gif3(cv::Mat guidedImg, cv::Mat inputP, int r, int r2, double eps, double namuda, double h, cv::Mat& beta_)
+{ return mdisp::getGuidedFilter_ours_gif3(guidedImg, inputP, r, r2, eps, namuda, h, beta_); }
 inline void steerFilter(cv::Mat src, cv::Mat& dst) { mdisp::steerFilter(src, dst); }
 
 // methods/methods.h:33

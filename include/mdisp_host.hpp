@@ -75,7 +75,7 @@ enum CENSUS_ALGORITHM {   // methods_disp.h:18-27
     BASIC_CENSUS = MDISP_BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS,
     STATISTIC_MULTISCALE_CENSUS, CENSUS_2017
 };
-enum GIF_TYPE { GIF = MDISP_GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 };   // gifs.h:4-13; OURS_* are rejected as unsupported
+enum GIF_TYPE { GIF = MDISP_GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 };   // gifs.h:4-13
 
 // StereoMatchParam, methods_disp.h:5-16
 template <class M> struct StereoMatchParamT {
@@ -208,6 +208,13 @@ template <class M> M getGuidedFilter_egif(M guidedImg, M inputP, int r, double e
 { return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_EGIF, nullptr, 0, 0.0, &beta); }
 template <class M> M getGuidedFilter_skwgif2(M guidedImg, M inputP, M steerFilterW, int r, int r2, double eps, double namuda, double h = 0.5)
 { (void)h; return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_SKWGIF, &steerFilterW, r2, namuda, nullptr); }
+// gifs.h:36-38 (`h` is accepted and unused, as in the reference)
+template <class M> M getGuidedFilter_ours_gif(M guidedImg, M inputP, int r, int r2, double eps, double namuda, double h)
+{ (void)h; return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_OURS_GIF, nullptr, r2, namuda, nullptr); }
+template <class M> M getGuidedFilter_ours_gif2(M guidedImg, M inputP, int r, int r2, double eps, double namuda, double h)
+{ (void)h; return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_OURS_GIF2, nullptr, r2, namuda, nullptr); }
+template <class M> M getGuidedFilter_ours_gif3(M guidedImg, M inputP, int r, int r2, double eps, double namuda, double h, M& beta_)
+{ (void)h; return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_OURS_GIF3, nullptr, r2, namuda, &beta_); }
 
 // steerFilter.h:39 -> CV_64F
 template <class M> void steerFilter(M src, M& dst)

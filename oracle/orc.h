@@ -46,7 +46,7 @@ enum {
 enum { ORC_SAT_F32 = 0, ORC_SAT_INT = 1 };
 
 enum {
-    ORC_GIF = 0, ORC_WGIF = 1, ORC_EGIF = 2, ORC_SKWGIF = 3
+    ORC_GIF = 0, ORC_WGIF = 1, ORC_EGIF = 2, ORC_SKWGIF = 3, ORC_OURS_GIF = 4, ORC_OURS_GIF2 = 5, ORC_OURS_GIF3 = 6
 };
 
 typedef struct {
@@ -100,6 +100,9 @@ void orc_guided_filter_wgif(const float* guideN, const float* pN, int H, int W, 
 void orc_guided_filter_skwgif2(const float* guideN, const float* pN, const double* steerW, int H, int W,
                                int r, int r2, double eps, double namuda, float* out);
 void orc_steer_filter(const uint8_t* src, int H, int W, double* dst);
+void orc_bilateral_f32(const float* src, int H, int W, int d, double sigma_color, double sigma_space, float* dst);
+void orc_guided_filter_ours(const float* guideN, const float* pN, int H, int W, int r, int r2, double eps, double namuda,
+                            int variant /* 1, 2, 3 */, float* out, float* beta /* nullable */);
 int  orc_asw_gifs(const uint8_t* guide, const float* costs /*D*H*W f32*/, int H, int W, int D, int minD,
                   int winSize, double eps, int gifType, int r2, double namuda, float* disp, float* filtered /*nullable*/);
 

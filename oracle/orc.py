@@ -16,7 +16,7 @@ BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCA
     STATISTIC_MULTISCALE_CENSUS, CENSUS_2017 = range(7)
 AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
 SAT_F32, SAT_INT = 0, 1
-GIF, WGIF, EGIF, SKWGIF = range(4)
+GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 = range(7)
 
 
 class orc_sgm_params(C.Structure):
@@ -188,9 +188,22 @@ def guided_filter(guide, P, r, eps, gif_type=GIF, steerW=None, r2=5, namuda=0.1,
     elif gif_type == SKWGIF:
         sw = np.ascontiguousarray(steerW, np.float64)
         L.orc_guided_filter_skwgif2(_p(G), _p(Pn), _p(sw), H, W, r, r2, d(eps), d(namuda), _p(out))
+    elif gif_type in (OURS_GIF, OURS_GIF2, OURS_GIF3):
+        beta = np.empty((H, W), np.float32)
+        L.orc_guided_filter_ours(_p(G), _p(Pn), H, W, r, r2, d(eps), d(namuda), gif_type - OURS_GIF + 1, _p(out), _p(beta))
+        if want_beta:
+            return out, beta
     else:
         raise ValueError(gif_type)
     return out
+
+
+def bilateral_filter(src, d, sigma_color, sigma_space):
+    src = np.ascontiguousarray(src, np.float32)
+    H, W = src.shape
+    dst = np.empty((H, W), np.float32)
+    lib().orc_bilateral_f32(_p(src), H, W, d, C.c_double(sigma_color), C.c_double(sigma_space), _p(dst))
+    return dst
 
 
 def asw_gifs(guide, costs, minD, winSize, eps, gif_type=GIF, r2=5, namuda=0.1, want_filtered=False):

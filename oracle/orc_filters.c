@@ -284,6 +284,138 @@ void orc_guided_filter_skwgif2(const float* G, const float* P, const double* ste
     free(meanG2); free(corrG2); free(t); free(temp); free(a); free(b); free(sw); gif_free(&s);
 }
 
+/*
+ * cv::bilateralFilter(src, dst, d, sigmaColor, sigmaSpace) on a CV_32FC1 image, restated from the
+ * published OpenCV 4.1.0 imgproc algorithm (bilateralFilter_32f and the scalar loop of
+ * BilateralFilter_32f_Invoker; the library itself is not part of the reference tree): radius = d/2
+ * (at least 1; cvRound(1.5*sigmaSpace) when d <= 0), BORDER_REFLECT_101, circular footprint,
+ * float space weights, colour weights from a 4096-bin table over [0, max-min] with linear
+ * interpolation, float accumulation in footprint order, and a plain copy when the image is flat.
+ */
+void orc_bilateral_f32(const float* src, int H, int W, int d, double sigma_color, double sigma_space, float* dst)
+{
+    long N = (long)H * W;
+    if (sigma_color <= 0) sigma_color = 1;
+    if (sigma_space <= 0) sigma_space = 1;
+    double gcc = -0.5 / (sigma_color * sigma_color), gsc = -0.5 / (sigma_space * sigma_space);
+    int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+    if (radius < 1) radius = 1;
+    d = radius * 2 + 1;
+    float mn = src[0], mx = src[0];
+    for (long i = 0; i < N; i++) { if (src[i] < mn) mn = src[i]; if (src[i] > mx) mx = src[i]; }
+    double minV = mn, maxV = mx;
+    if (fabs(minV - maxV) < FLT_EPSILON) { memcpy(dst, src, sizeof(float) * (size_t)N); return; }
+    int tw = W + 2 * radius, th = H + 2 * radius;
+    float* temp = fnew((long)tw * th);
+    for (int y = 0; y < th; y++)
+        for (int x = 0; x < tw; x++)
+            temp[(long)y * tw + x] = src[(long)orc_reflect101(y - radius, H) * W + orc_reflect101(x - radius, W)];
+    const int kExpNumBins = 1 << 12;
+    float len = (float)(maxV - minV);
+    float scale_index = kExpNumBins / len;
+    float* expLUT = fnew(kExpNumBins + 2);
+    float lastExpVal = 1.f;
+    for (int i = 0; i < kExpNumBins + 2; i++) {
+        if (lastExpVal > 0.f) {
+            double val = i / scale_index;
+            expLUT[i] = (float)exp(val * val * gcc);
+            lastExpVal = expLUT[i];
+        } else expLUT[i] = 0.f;
+    }
+    float* sw = fnew((long)d * d);
+    int* so = (int*)malloc(sizeof(int) * (size_t)d * d);
+    int maxk = 0;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            double r = sqrt((double)i * i + (double)j * j);
+            if (r > radius) continue;
+            sw[maxk] = (float)exp(r * r * gsc);
+            so[maxk++] = i * tw + j;
+        }
+#pragma omp parallel for
+    for (int y = 0; y < H; y++) {
+        const float* sp = temp + (long)(y + radius) * tw + radius;
+        for (int x = 0; x < W; x++) {
+            float sum = 0, wsum = 0;
+            float val0 = sp[x];
+            for (int k = 0; k < maxk; k++) {
+                float val = sp[x + so[k]];
+                float alpha = (float)(fabsf(val - val0) * scale_index);
+                int idx = (int)floorf(alpha);
+                alpha -= idx;
+                volatile float dl = expLUT[idx + 1] - expLUT[idx];
+                volatile float t = alpha * dl;
+                volatile float cw = expLUT[idx] + t;
+                volatile float w = sw[k] * cw;
+                volatile float vw = val * w;
+                sum += vw;
+                wsum += w;
+            }
+            dst[(long)y * W + x] = sum / wsum;
+        }
+    }
+    free(temp); free(expLUT); free(sw); free(so);
+}
+
+/*
+ * getGuidedFilter_ours_gif / _ours_gif2 / _ours_gif3, gifs.cpp:620-669, 672-725, 728-804: the
+ * coefficients a, b of the WGIF-like (gamma from the r2-window variance), plain and EGIF-like
+ * guided filter, then bilateralFilter(a), bilateralFilter(b) with sigmaColor 2, sigmaSpace 3 and
+ * diameter r2 (variants 1, 2) or r (variant 3), and a_bil*G + b_bil.  beta (variant 3, :791-800)
+ * = a_bil / (1 - a_bil).
+ */
+void orc_guided_filter_ours(const float* G, const float* P, int H, int W, int r, int r2, double eps, double namuda,
+                            int variant, float* out, float* beta)
+{
+    long N = (long)H * W;
+    gif_stats s = gif_front(G, P, H, W, r);
+    float* a = fnew(N); float* b = fnew(N); float* den = fnew(N);
+    float epsf = (float)eps;
+    if (variant == 1) {
+        float* meanG2 = fnew(N); float* corrG2 = fnew(N); float* t = fnew(N); float* temp = fnew(N);
+        orc_box_filter_f32(G, H, W, r2, r2, 1, meanG2);
+        mul_f(G, G, N, t);
+        orc_box_filter_f32(t, H, W, r2, r2, 1, corrG2);
+        double sum = 0;
+        for (long i = 0; i < N; i++) {
+            volatile float m2 = meanG2[i] * meanG2[i];
+            volatile float v2 = corrG2[i] - m2;
+            temp[i] = v2 + (float)namuda;                      /* (:646) */
+            sum += (double)(1.0f / temp[i]);
+        }
+        float gscale = (float)(sum / ((double)H * W));         /* (:647) */
+        for (long i = 0; i < N; i++) {
+            volatile float gamma = temp[i] * gscale;
+            volatile float e = epsf / gamma;
+            den[i] = s.varG[i] + e;                            /* (:652) */
+        }
+        free(meanG2); free(corrG2); free(t); free(temp);
+    } else if (variant == 2) {
+        for (long i = 0; i < N; i++) den[i] = s.varG[i] + epsf;   /* (:706) */
+    } else {
+        double sum = 0;
+        for (long i = 0; i < N; i++) sum += (double)s.varG[i];
+        double mean2Var = sum / ((double)W * H);               /* (:753) */
+        float add = (float)(mean2Var * eps + 0.001 * 0.001);
+        for (long i = 0; i < N; i++) den[i] = s.varG[i] + add; /* (:754) */
+    }
+    for (long i = 0; i < N; i++) {
+        a[i] = s.covGP[i] / den[i];
+        volatile float t = a[i] * s.meanG[i];
+        b[i] = s.meanP[i] - t;
+    }
+    float* ma = fnew(N); float* mb = fnew(N);
+    int d = variant == 3 ? r : r2;
+    orc_bilateral_f32(a, H, W, d, 2, 3, ma);
+    orc_bilateral_f32(b, H, W, d, 2, 3, mb);
+    for (long i = 0; i < N; i++) {
+        if (beta) { volatile float om = 1.0f - ma[i]; beta[i] = ma[i] / om; }
+        volatile float t = ma[i] * G[i];
+        out[i] = t + mb[i];
+    }
+    free(a); free(b); free(den); free(ma); free(mb); gif_free(&s);
+}
+
 /* basis functions sampled at integer taps, steerFilter.cpp:3-87 */
 static double G2a(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 0.9213 * ((2 * xs) - 1) * ys; }
 static double G2b(int x, int y) { double xs = x * x, ys = y * y; ys = exp(-(xs + ys)); return 1.843 * x * y * ys; }
@@ -375,6 +507,8 @@ int orc_asw_gifs(const uint8_t* guide, const float* costs, int H, int W, int D, 
         case ORC_WGIF: orc_guided_filter_wgif(G, P, H, W, winSize, eps, o); break;
         case ORC_EGIF: orc_guided_filter_egif(G, P, H, W, winSize, eps, o, NULL); break;
         case ORC_SKWGIF: orc_guided_filter_skwgif2(G, P, steer, H, W, winSize, r2, eps, namuda, o); break;
+        case ORC_OURS_GIF: case ORC_OURS_GIF2: case ORC_OURS_GIF3:
+            orc_guided_filter_ours(G, P, H, W, winSize, r2, eps, namuda, gifType - ORC_OURS_GIF + 1, o, NULL); break;
         default: return -2;
         }
         if (filtered) memcpy(filtered + (long)k * N, o, sizeof(float) * N);

@@ -52,7 +52,7 @@ for (H, W, D, win) in ((480, 640, 64, 7), (1080, 1920, 256, 7)):
 H, W, D = 480, 640, 64
 L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
 p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=7, minDisparity=0, maxDisparity=D - 1, isDispLeft=True)
-for name, gif in (("GIF", api.GIF), ("EGIF", api.EGIF), ("SKWGIF", api.SKWGIF)):
+for name, gif in (("GIF", api.GIF), ("EGIF", api.EGIF), ("SKWGIF", api.SKWGIF), ("OURS_GIF", api.OURS_GIF), ("OURS_GIF3", api.OURS_GIF3)):
     dt, r = host_rate(lambda: api.asw_gifs(p, 0.01, gif, 15, 0.1, 0.5, api.COST_CENSUS), H, W, D)
     print(f"asw_gifs {name:7s} {W}x{H} D={D} host API (copies included): {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
 dt, r = host_rate(lambda: api.computeSAD_BFOpti(p), H, W, D)

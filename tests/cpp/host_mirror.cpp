@@ -41,7 +41,9 @@ int main(int argc, char** argv)
     sgbmCompute(L, R, sp, d16);                                    // CV_16S
     Mat cen;
     countCensusImg(L, cen);
-    if (dCensus.empty() || dSad.empty() || d16.empty() || cen.empty()) return fail("empty output");
+    // the call the reference's main() makes (cameraCalibration.cpp:174), with census costs in place of dense SIFT
+    Mat dOurs = asw_gifs(p, 0.01, OURS_GIF3, 15, 0.01, 0.5);       // CV_32F
+    if (dCensus.empty() || dSad.empty() || d16.empty() || cen.empty() || dOurs.empty()) return fail("empty output");
     FILE* f = std::fopen(argv[5], "wb");
     if (!f) return fail("open output");
     std::fwrite(L.data(), 1, (size_t)H * W, f);
@@ -50,6 +52,7 @@ int main(int argc, char** argv)
     std::fwrite(dSad.data(), 1, (size_t)H * W, f);
     std::fwrite(d16.data(), 2, (size_t)H * W, f);
     std::fwrite(cen.data(), 1, (size_t)H * W, f);
+    std::fwrite(dOurs.data(), 4, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

@@ -80,6 +80,33 @@ def test_guided_filter_skwgif2(api, orc, shape, r, r2):
     assert np.abs(got - exp).max() <= TOL
 
 
+@pytest.mark.parametrize("shape,r,r2", [((48, 64), 7, 5), ((40, 56), 9, 15), ((70, 45), 5, 7), ((30, 100), 15, 3)])
+def test_guided_filter_ours(api, orc, shape, r, r2):
+    # bilateral-smoothed coefficients (gifs.cpp:620-804); the reference's main() runs OURS_GIF3
+    guide = _textured(8, *shape)
+    rng = np.random.default_rng(9)
+    P = rng.integers(0, 9, shape, dtype=np.uint8)
+    for eps in (1e-2, 1e-4):
+        got = api.getGuidedFilter_ours_gif(guide, P, r, r2, eps, 0.01)
+        assert np.abs(got - orc.guided_filter(guide, P, r, eps, orc.OURS_GIF, r2=r2, namuda=0.01)).max() <= TOL
+        got = api.getGuidedFilter_ours_gif2(guide, P, r, r2, eps, 0.01)
+        assert np.abs(got - orc.guided_filter(guide, P, r, eps, orc.OURS_GIF2, r2=r2, namuda=0.01)).max() <= TOL
+        got, beta = api.getGuidedFilter_ours_gif3(guide, P, r, r2, eps, 0.01)
+        exp, ebeta = orc.guided_filter(guide, P, r, eps, orc.OURS_GIF3, r2=r2, namuda=0.01, want_beta=True)
+        assert np.abs(got - exp).max() <= TOL
+        ok = np.abs(ebeta) < 1e3                      # a_bil close to 1 makes beta = a/(1-a) ill-conditioned
+        assert np.abs(beta - ebeta)[ok].max() <= TOL * max(1.0, np.abs(ebeta[ok]).max())
+
+
+def test_guided_filter_ours_flat_slice(api, orc):
+    # a constant slice gives a = 0 everywhere: cv::bilateralFilter copies a flat image
+    guide = _textured(10, 40, 50)
+    P = np.full((40, 50), 3, np.uint8)
+    for fn, t in ((api.getGuidedFilter_ours_gif, orc.OURS_GIF), (api.getGuidedFilter_ours_gif2, orc.OURS_GIF2)):
+        got = fn(guide, P, 7, 5, 0.01, 0.01)
+        assert np.abs(got - orc.guided_filter(guide, P, 7, 0.01, t, r2=5, namuda=0.01)).max() <= TOL
+
+
 @pytest.mark.parametrize("left", [True, False])
 def test_census_stereo_guided_is_the_reference_default(api, orc, left):
     L, R, _ = api.synth_pair(0x5EED0001, 96, 160, 32)
@@ -91,7 +118,7 @@ def test_census_stereo_guided_is_the_reference_default(api, orc, left):
     assert _tie_aware_equal(got, exp, costs, 0)
 
 
-@pytest.mark.parametrize("gif", [0, 1, 2, 3])
+@pytest.mark.parametrize("gif", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("source", ["census", "absdiff", "volume"])
 def test_asw_gifs(api, orc, gif, source):
     H, W, minD, maxD, win = 64, 96, 2, 17, 7
@@ -120,7 +147,7 @@ def test_asw_gifs(api, orc, gif, source):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gif,win,r2", [(0, 7, 5), (3, 9, 15), (2, 11, 5), (3, 35, 15)])
+@pytest.mark.parametrize("gif,win,r2", [(0, 7, 5), (3, 9, 15), (2, 11, 5), (3, 35, 15), (4, 7, 15), (6, 9, 15)])
 def test_row_bands_equal_the_full_image(api, gif, win, r2):
     # the row-band entry point (one GPU's share of a large pair) reproduces the rows of a full call bit for bit
     import torch

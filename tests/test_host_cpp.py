@@ -29,7 +29,8 @@ def test_cv_adapter_names_every_boundary_function():
     # the OpenCV adapter cannot be compiled here (no OpenCV); check that it declares the reference's names
     text = open(os.path.join(ROOT, "include", "mdisp_cv.hpp")).read()
     for name in ("computeSAD_inteOpti", "computeSAD_BFOpti", "censusStereo", "asw_gifs", "countCensusImg", "countHummingDist",
-                 "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "steerFilter",
+                 "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "getGuidedFilter_ours_gif", "getGuidedFilter_ours_gif2",
+                 "getGuidedFilter_ours_gif3", "steerFilter",
                  "getDisparity_SGBM", "StereoMatchParam"):
         assert name in text
 
@@ -48,8 +49,17 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     dC = buf[o:o + 8 * n].view(np.float64).reshape(H, W); o += 8 * n
     dS = buf[o:o + n].reshape(H, W); o += n
     d16 = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
-    cen = buf[o:o + n].reshape(H, W)
+    cen = buf[o:o + n].reshape(H, W); o += n
+    dO = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
     assert np.array_equal(dC, orc.census_stereo(L, R, 7, 0, maxD, True, orc.BASIC_CENSUS, orc.AGG_BOX))
     assert np.array_equal(dS, orc.sad_box(L, R, 7, 0, maxD, True))
     assert np.array_equal(d16, orc.sgm(L, R, 0, maxD + 1, 8, 32, 10, 1, 8, 1))
     assert np.array_equal(cen, orc.census(L, orc.BASIC_CENSUS, 0))
+    pad = orc.pad_reflect_lr(R, maxD, 0)
+    cL, cP = orc.census(L), orc.census(pad)
+    costs = np.stack([orc.hamming(cL, np.ascontiguousarray(cP[:, maxD - d:maxD - d + W])) for d in range(maxD + 1)]).astype(np.float32)
+    exp, filt = orc.asw_gifs(L, costs, 0, 7, 0.01, orc.OURS_GIF3, 15, 0.01, want_filtered=True)
+    bad = dO != exp
+    assert bad.mean() < 1e-3
+    for y, x in zip(*np.nonzero(bad)):          # float WTA: only near-ties may differ
+        assert abs(filt[int(dO[y, x]), y, x] - filt[int(exp[y, x]), y, x]) < 1e-5
