@@ -27,6 +27,12 @@ class mdisp_param(C.Structure):
     _fields_ = [("winSize", C.c_int), ("minDisparity", C.c_int), ("maxDisparity", C.c_int), ("isDispLeft", C.c_int)]
 
 
+class mdisp_stereosgbm_params(C.Structure):
+    """cv::StereoSGBM::create arguments, in its order"""
+    _fields_ = [(n, C.c_int) for n in ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff", "preFilterCap",
+                                       "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
+
+
 class mdisp_sgbm_params(C.Structure):
     _fields_ = [("minDisparity", C.c_int), ("numDisparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
                 ("uniquenessRatio", C.c_int), ("disp12MaxDiff", C.c_int), ("paths", C.c_int), ("subpixel", C.c_int),
@@ -41,6 +47,8 @@ EXPORTS = [
     "mdisp_build_rectify_maps", "mdisp_stereo_rectify", "mdisp_remap", "mdisp_reproject_q", "mdisp_reproject_triangulate", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
+    "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
+    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev",
 ]
 
 _lib = None
@@ -87,6 +95,14 @@ def load():
     lib.mdisp_remap.argtypes = [vp, img, vp, vp, img]
     lib.mdisp_sgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, sgp]
     lib.mdisp_sgbm_workspace_bytes.restype = C.c_size_t
+    ssp = P(mdisp_stereosgbm_params)
+    lib.mdisp_stereosgbm_compute.argtypes = [vp, img, img, ssp, img]
+    lib.mdisp_stereosgbm_stages.argtypes = [vp, img, img, ssp, img, vp, img]
+    lib.mdisp_median_blur3_s16.argtypes = [vp, img, img]
+    lib.mdisp_filter_speckles_s16.argtypes = [vp, img, C.c_int, C.c_int, C.c_int]
+    lib.mdisp_stereosgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, ssp]
+    lib.mdisp_stereosgbm_workspace_bytes.restype = C.c_size_t
+    lib.mdisp_stereosgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, ssp, vp, vp, C.c_size_t]
     lib.mdisp_sgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_sgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, sgp]
     lib.mdisp_sgbm_batch_workspace_bytes.restype = C.c_size_t

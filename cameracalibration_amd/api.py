@@ -11,7 +11,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import MdispError, check, image, load, mdisp_param, mdisp_sgbm_params
+from ._lib import MdispError, check, image, load, mdisp_param, mdisp_sgbm_params, mdisp_stereosgbm_params
 
 # CENSUS_ALGORITHM, methods_disp.h:18-27
 BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS, \
@@ -234,13 +234,67 @@ def sgbm_volume(srcLeft, srcRight, params, ctx=None):
     return S
 
 
+MODE_SGBM, MODE_HH = 0, 1
+
+
+def StereoSGBM_create(minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
+                      uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=MODE_SGBM):
+    """cv::StereoSGBM::create with its argument order and defaults -> parameter block."""
+    return mdisp_stereosgbm_params(minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+                                   speckleWindowSize, speckleRange, mode)
+
+
+def _u8_image(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim not in (2, 3):
+        raise ValueError("expected HxW or HxWxC uint8")
+    return a
+
+
+def stereosgbm_compute(left, right, params, want_cost=False, want_raw=False, ctx=None):
+    """cv::StereoSGBM::compute (Birchfield-Tomasi block cost, MODE_SGBM / MODE_HH, median, speckles) -> CV_16S x16.
+    want_cost: also the block cost volume int16 [H][W - minD - D][D]; want_raw: also the map before the median."""
+    L, R = _u8_image(left), _u8_image(right)
+    H, W = L.shape[:2]
+    out = np.empty((H, W), dtype=np.int16)
+    if not (want_cost or want_raw):
+        check(load().mdisp_stereosgbm_compute(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(params), C.byref(image(out))))
+        return out
+    W1 = max(W - params.minDisparity - params.numDisparities, 0)
+    cost = np.empty((H, W1, params.numDisparities), dtype=np.int16) if want_cost else None
+    raw = np.empty((H, W), dtype=np.int16) if want_raw else None
+    check(load().mdisp_stereosgbm_stages(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(params), C.byref(image(out)),
+                                         cost.ctypes.data if want_cost else None, C.byref(image(raw)) if want_raw else None))
+    res = [out]
+    if want_cost:
+        res.append(cost)
+    if want_raw:
+        res.append(raw)
+    return tuple(res)
+
+
+def medianBlur3(src, ctx=None):
+    """cv::medianBlur(src, dst, 3) on CV_16SC1."""
+    a = np.ascontiguousarray(src, dtype=np.int16)
+    dst = np.empty_like(a)
+    check(load().mdisp_median_blur3_s16(_ctx(ctx), C.byref(image(a)), C.byref(image(dst))))
+    return dst
+
+
+def filterSpeckles(img, newVal, maxSpeckleSize, maxDiff, ctx=None):
+    """cv::filterSpeckles on CV_16SC1; returns the filtered copy."""
+    a = np.ascontiguousarray(img, dtype=np.int16).copy()
+    check(load().mdisp_filter_speckles_s16(_ctx(ctx), C.byref(image(a)), newVal, maxSpeckleSize, maxDiff))
+    return a
+
+
 def getDisparity_SGBM(srcLeft, srcRight, ctx=None):
-    """methods/methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7) then `disp / 16`
+    """methods/methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7)->compute, then `disp / 16`
     (a CV_16S MatExpr divide: round half to even)."""
     if srcLeft is None or srcRight is None:
         print(" --(!) Error reading images ")
         return None
-    d16 = sgbm_compute(srcLeft, srcRight, sgbm_params(0, 48, paths=5), ctx)
+    d16 = stereosgbm_compute(srcLeft, srcRight, StereoSGBM_create(0, 48, 7), ctx=ctx)
     return np.rint(d16.astype(np.float64) / 16.0).astype(np.int16)
 
 

@@ -633,6 +633,108 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     return md_check_sgm_error(c);
 }
 
+// Upload an 8-bit 1- or 3-channel image as it is (interleaved), rows at `dpitch`
+static int upload_u8(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch)
+{
+    MD_REQUIRE(im->depth == MDISP_8U && (im->channels == 1 || im->channels == 3), MDISP_E_UNSUPPORTED,
+               "only CV_8UC1 / CV_8UC3 images are supported (got depth %d, %d channels)", im->depth, im->channels);
+    return md_h2d_2d(c, d, dpitch, im->data, im->step_bytes, (size_t)im->cols * im->channels, im->rows);
+}
+
+extern "C" int mdisp_stereosgbm_stages(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_stereosgbm_params* p,
+                                       mdisp_image* out, int16_t* cost, mdisp_image* raw)
+{
+    MD_REQUIRE(c && p, MDISP_E_BADARG, "null argument");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols && L->channels == R->channels && L->depth == R->depth, MDISP_E_BADARG,
+               "left/right size or type mismatch");
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_16S, 1, "out"))) return rc;
+    if (raw && (rc = check_out(raw, L->rows, L->cols, MDISP_16S, 1, "raw"))) return rc;
+    MD_REQUIRE(p->numDisparities > 0 && p->minDisparity >= 0, MDISP_E_BADARG, "bad disparity range");
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols, cn = L->channels;
+    const int W1 = W - p->minDisparity - p->numDisparities;
+    const size_t pitch = md_align((size_t)W * cn, 256), V = W1 > 0 ? (size_t)H * W1 * p->numDisparities : 0;
+    Carver cv;
+    size_t o_ws = cv.take(md_stereosgbm_bytes(H, W, cn, p)), o_l = cv.take(pitch * H), o_r = cv.take(pitch * H),
+           o_d = cv.take((size_t)H * W * 2), o_raw = cv.take((size_t)H * W * 2), o_c = cv.take(cost ? V * 2 : 0);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_u8(c, L, base + o_l, pitch)) || (rc = upload_u8(c, R, base + o_r, pitch))) return rc;
+    if ((rc = md_stereosgbm_run(c->stream, base + o_l, base + o_r, pitch, H, W, cn, p, (int16_t*)(base + o_d), base + o_ws,
+                                cost ? (int16_t*)(base + o_c) : nullptr, raw ? (int16_t*)(base + o_raw) : nullptr)))
+        return rc;
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H));
+    if (raw) MD_TRY(md_d2h_2d(c, raw->data, raw->step_bytes, base + o_raw, (size_t)W * 2, (size_t)W * 2, H));
+    if (cost && V) MD_HIP(hipMemcpyAsync(cost, base + o_c, V * 2, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_stereosgbm_compute(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_stereosgbm_params* p,
+                                        mdisp_image* out)
+{
+    return mdisp_stereosgbm_stages(c, L, R, p, out, nullptr, nullptr);
+}
+
+extern "C" size_t mdisp_stereosgbm_workspace_bytes(int rows, int cols, int channels, const mdisp_stereosgbm_params* p)
+{
+    if (!p || rows <= 0 || cols <= 0 || p->numDisparities <= 0 || p->minDisparity < 0) return 0;
+    return md_stereosgbm_bytes(rows, cols, channels, p);
+}
+
+extern "C" int mdisp_stereosgbm_dev(mdisp_ctx* c, const uint8_t* dL, const uint8_t* dR, int rows, int cols, int channels, size_t pitch,
+                                    const mdisp_stereosgbm_params* p, int16_t* dDisp, void* ws, size_t ws_bytes)
+{
+    MD_REQUIRE(c && dL && dR && dDisp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(rows > 0 && cols > 0 && (channels == 1 || channels == 3) && pitch >= (size_t)cols * channels, MDISP_E_BADARG, "bad geometry");
+    MD_REQUIRE(p->numDisparities > 0 && p->minDisparity >= 0, MDISP_E_BADARG, "bad disparity range");
+    MD_HIP(hipSetDevice(c->device));
+    const size_t need = md_stereosgbm_bytes(rows, cols, channels, p);
+    if (ws) MD_REQUIRE(ws_bytes >= need, MDISP_E_NOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+    else if (!(ws = mdisp_ws(c, need))) return MDISP_E_NOMEM;
+    return md_stereosgbm_run(c->stream, dL, dR, pitch, rows, cols, channels, p, dDisp, ws, nullptr, nullptr);
+}
+
+extern "C" int mdisp_median_blur3_s16(mdisp_ctx* c, const mdisp_image* src, mdisp_image* dst)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(src, "src"))) return rc;
+    MD_REQUIRE(src->depth == MDISP_16S && src->channels == 1, MDISP_E_UNSUPPORTED, "medianBlur(3) is built for CV_16SC1");
+    if ((rc = check_out(dst, src->rows, src->cols, MDISP_16S, 1, "dst"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = src->rows, W = src->cols;
+    const size_t n = md_align((size_t)H * W * 2, 256);
+    u8* base = (u8*)mdisp_ws(c, 2 * n);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base, (size_t)W * 2, src->data, src->step_bytes, (size_t)W * 2, H));
+    MD_TRY(md_median3_s16(c->stream, (const int16_t*)base, H, W, (int16_t*)(base + n)));
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + n, (size_t)W * 2, (size_t)W * 2, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_filter_speckles_s16(mdisp_ctx* c, mdisp_image* img, int newVal, int maxSpeckleSize, int maxDiff)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(img, "img"))) return rc;
+    MD_REQUIRE(img->depth == MDISP_16S && img->channels == 1, MDISP_E_UNSUPPORTED, "filterSpeckles is built for CV_16SC1");
+    MD_REQUIRE((size_t)img->rows * img->cols < ((size_t)1 << 30), MDISP_E_RANGE, "image too large");
+    MD_HIP(hipSetDevice(c->device));
+    const int H = img->rows, W = img->cols;
+    const size_t n = md_align((size_t)H * W * 2, 256);
+    u8* base = (u8*)mdisp_ws(c, n + md_speckle_scratch_bytes(H, W));
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base, (size_t)W * 2, img->data, img->step_bytes, (size_t)W * 2, H));
+    MD_TRY(md_filter_speckles_s16(c->stream, (int16_t*)base, H, W, newVal, maxSpeckleSize, maxDiff, base + n));
+    MD_TRY(md_d2h_2d(c, img->data, img->step_bytes, base, (size_t)W * 2, (size_t)W * 2, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* Sh)
 {
     MD_REQUIRE(c && Sh, MDISP_E_BADARG, "null argument");

@@ -99,6 +99,14 @@ int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* 
 // aggregation only; *S receives the device volume (pixel stride plan.sstride)
 int md_sgm_aggregate_only(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, void* ws, const u16** S);
 
+// sgbm_bt.hip: cv::StereoSGBM with its own Birchfield-Tomasi block cost
+size_t md_stereosgbm_bytes(int H, int W, int cn, const mdisp_stereosgbm_params* p);
+int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int cn,
+                      const mdisp_stereosgbm_params* p, int16_t* dDisp, void* ws, int16_t* dCost, int16_t* dRaw);
+int md_median3_s16(hipStream_t s, const int16_t* src, int H, int W, int16_t* dst);
+size_t md_speckle_scratch_bytes(int H, int W);
+int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal, int maxSize, int maxDiff, void* scratch);
+
 // stereo.hip
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                     int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op);

@@ -1,0 +1,426 @@
+// cv::StereoSGBM::compute on gfx950 with the library's own matching cost: x-Sobel prefilter +
+// Birchfield-Tomasi pixel cost + block sum, MODE_SGBM (5 paths) / MODE_HH (8 paths) aggregation with
+// 16-bit saturating sums, winner-take-all + uniqueness + x16 parabola + disp12MaxDiff, then
+// medianBlur(3) and filterSpeckles.  Replaces the call sites of
+// cameraCalibration/methods/methods.cpp:1883-1921 (`StereoSGBM::create(0, 48, 7)`), :1216-1219 and
+// :1565-1568 (`create(0,64,7,490,1960,1,63,10,100,32,MODE_SGBM)`).  OpenCV 4.1.0's stereosgbm.cpp
+// is not part of the reference tree; its published algorithm is restated here (conventions listed
+// at the kernels).
+#include "common.h"
+
+namespace {
+
+struct BtGeom {
+    int H, W, cn, D, minD, W1, minX1, ftzero, bs;
+    size_t N;         // H*W, elements per plane
+};
+
+// planes [2*cn][H][W]: clipped x-Sobel of channel c (rows replicated at the top / bottom), then the
+// raw channel; columns 0 and W-1 of every plane hold ftzero
+__global__ __launch_bounds__(256) void bt_planes_kernel(const u8* __restrict__ img, size_t pitch, BtGeom g, u8* __restrict__ pl)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    const int cn = g.cn;
+    const u8* r1 = img + (size_t)y * pitch;
+    const u8* r0 = img + (size_t)(y > 0 ? y - 1 : y) * pitch;
+    const u8* r2 = img + (size_t)(y < g.H - 1 ? y + 1 : y) * pitch;
+    for (int c = 0; c < cn; c++) {
+        int s = g.ftzero, raw = g.ftzero;
+        if (x > 0 && x < g.W - 1) {
+            const int a = (x + 1) * cn + c, b = (x - 1) * cn + c;
+            const int v = ((int)r1[a] - (int)r1[b]) * 2 + (int)r0[a] - (int)r0[b] + (int)r2[a] - (int)r2[b];
+            s = min(max(v, -g.ftzero), g.ftzero) + g.ftzero;
+            raw = r1[x * cn + c];
+        }
+        pl[(size_t)c * g.N + (size_t)y * g.W + x] = (u8)s;
+        pl[(size_t)(cn + c) * g.N + (size_t)y * g.W + x] = (u8)raw;
+    }
+}
+
+__device__ __forceinline__ int bt_one(const u8* __restrict__ a, const u8* __restrict__ b, int W, int x, int x2)
+{
+    const int u = a[x];
+    const int ul = x > 0 ? (u + a[x - 1]) / 2 : u, ur = x < W - 1 ? (u + a[x + 1]) / 2 : u;
+    const int u0 = min(min(ul, ur), u), u1 = max(max(ul, ur), u);
+    const int v = b[x2];
+    const int vl = x2 > 0 ? (v + b[x2 - 1]) / 2 : v, vr = x2 < W - 1 ? (v + b[x2 + 1]) / 2 : v;
+    const int v0 = min(min(vl, vr), v), v1 = max(max(vl, vr), v);
+    const int c0 = max(max(0, u - v1), v0 - u);
+    const int c1 = max(max(0, v - u1), u0 - v);
+    return min(c0, c1);
+}
+
+// pixel cost of the computed columns x in [minX1, W): pix[y][x1][k], disparity minD + k; the raw
+// planes count a quarter
+__global__ __launch_bounds__(256) void bt_cost_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
+                                                      int16_t* __restrict__ pix)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (e >= g.W1 * g.D) return;
+    const int x1 = e / g.D, k = e - x1 * g.D;
+    const int x = x1 + g.minX1, x2 = x - (g.minD + k);
+    int cost = 0;
+    for (int c = 0; c < 2 * g.cn; c++) {
+        const u8* a = p1 + (size_t)c * g.N + (size_t)y * g.W;
+        const u8* b = p2 + (size_t)c * g.N + (size_t)y * g.W;
+        cost += bt_one(a, b, g.W, x, x2) >> (c < g.cn ? 0 : 2);
+    }
+    pix[((size_t)y * g.W1 + x1) * g.D + k] = (int16_t)cost;
+}
+
+// horizontal (VERT = false) or vertical window sum with the window clamped to the computed
+// columns / the image rows; 16-bit wrap-around like the library's CostType arithmetic.  The
+// vertical pass gives the first computed column the block cost of row 0 in every row.
+template <bool VERT>
+__global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restrict__ in, BtGeom g, int16_t* __restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (e >= g.W1 * g.D) return;
+    const int x1 = e / g.D, k = e - x1 * g.D, h = g.bs / 2;
+    int s = 0;
+    if (VERT) {
+        const int yy = x1 == 0 ? 0 : y;
+        for (int i = -h; i <= h; i++) s += in[((size_t)min(max(yy + i, 0), g.H - 1) * g.W1 + x1) * g.D + k];
+    } else {
+        for (int i = -h; i <= h; i++) s += in[((size_t)y * g.W1 + min(max(x1 + i, 0), g.W1 - 1)) * g.D + k];
+    }
+    out[((size_t)y * g.W1 + x1) * g.D + k] = (int16_t)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One wave per scan line of the cropped W1 x H domain, lane l owns disparities l*ND .. l*ND+ND-1.
+// L_r = C + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, minL_r(p-r)+P2) - (minL_r(p-r)+P2),
+// zero outside the domain, stored as 16-bit values; the direction's costs are added into `acc`.
+#define BT_BIG 0x3FFF0000
+template <int ND> struct CVec;
+template <> struct CVec<1> { typedef int16_t type; };
+template <> struct CVec<2> { typedef u32 type; };
+template <> struct CVec<4> { typedef uint2 type; };
+template <> struct CVec<8> { typedef uint4 type; };
+
+struct PathArgs { const int16_t* C; int* acc; int H, W1, D, P1, P2; };
+
+template <int ND, bool FIRST>
+__global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
+{
+    const int lane = threadIdx.x & 63;
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= nlines) return;
+    const int H = a.H, W = a.W1, D = a.D;
+    int x0, y0;
+    if (dy == 0) { y0 = line; x0 = dx > 0 ? 0 : W - 1; }
+    else {
+        const int ys = dy > 0 ? 0 : H - 1;
+        if (line < W) { x0 = line; y0 = ys; }
+        else { const int i = line - W; y0 = dy > 0 ? 1 + i : H - 2 - i; x0 = dx > 0 ? 0 : W - 1; }
+    }
+    const int nx = dx > 0 ? W - x0 : (dx < 0 ? x0 + 1 : 0x7FFFFFFF);
+    const int ny = dy > 0 ? H - y0 : (dy < 0 ? y0 + 1 : 0x7FFFFFFF);
+    const int n = min(nx, ny);
+    const int k0 = lane * ND;
+    const bool mine = k0 < D;                 // D is a multiple of 16 >= ND, so a lane is all in or all out
+    int Lp[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) Lp[j] = mine ? 0 : 32767;    // L_r(., -1) = L_r(., D) = SHRT_MAX
+    int minPrev = 0;
+    const int P1 = a.P1, P2 = a.P2;
+    typedef typename CVec<ND>::type V;
+    V cnext = V();
+    auto fetch = [&](int t) {
+        if (mine) cnext = *reinterpret_cast<const V*>(a.C + ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0);
+    };
+    fetch(0);
+    for (int t = 0; t < n; t++) {
+        int16_t c[ND];
+        __builtin_memcpy(c, &cnext, sizeof(V));
+        if (t + 1 < n) fetch(t + 1);
+        int left = __shfl_up(Lp[ND - 1], 1, 64);
+        int right = __shfl_down(Lp[0], 1, 64);
+        if (lane == 0) left = 32767;
+        if (lane == 63) right = 32767;
+        const int delta = minPrev + P2;
+        int Ln[ND], mn = BT_BIG;
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+            const int lo = j > 0 ? Lp[j - 1] : left, hi = j < ND - 1 ? Lp[j + 1] : right;
+            int L = (int)c[j] + min(min(Lp[j], lo + P1), min(hi + P1, delta)) - delta;
+            L = (int)(int16_t)L;
+            if (!mine) L = BT_BIG;
+            Ln[j] = L;
+            mn = min(mn, L);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mn = min(mn, __shfl_xor(mn, m, 64));
+        if (mine) {
+            int* ap = a.acc + ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
+#pragma unroll
+            for (int j = 0; j < ND; j++) ap[j] = FIRST ? Ln[j] : ap[j] + Ln[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
+        minPrev = mn;
+    }
+}
+
+// S = saturate_cast<short>(S + acc)   (first group: S starts at zero)
+__global__ __launch_bounds__(256) void bt_saturate_kernel(const int* __restrict__ acc, size_t n, int first, int16_t* __restrict__ S)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int v = (first ? 0 : (int)S[i]) + acc[i];
+    S[i] = (int16_t)min(max(v, -32768), 32767);
+}
+
+struct SelArgs {
+    const int16_t* S; int H, W, W1, D, minD, minX1, uniq, maxDiff;
+    int16_t* disp;
+};
+// One workgroup per image row: first-minimum WTA, uniqueness, disp2 election (minimum S, ties to
+// the larger x: the library walks right to left with a strict '>'), x16 parabola, then the
+// disp12MaxDiff check.  Columns left of minX1 stay invalid.
+__global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
+{
+    extern __shared__ u32 lds[];
+    u32* key = lds;                                            // [W] (S + 32768) << 16 | (0xFFFF - x)
+    int16_t* d1 = reinterpret_cast<int16_t*>(lds + a.W);       // [W]
+    const int y = blockIdx.x, W = a.W, D = a.D;
+    const int INVALID = (a.minD - 1) * 16;
+    for (int i = threadIdx.x; i < W; i += 256) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int x1 = wv; x1 < a.W1; x1 += 4) {
+        const int16_t* sp = a.S + ((size_t)y * a.W1 + x1) * D;
+        u32 best = 0xFFFFFFFFu;
+        for (int k = lane; k < D; k += 64) best = min(best, ((u32)((int)sp[k] + 32768) << 16) | (u32)k);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) best = min(best, (u32)__shfl_xor((int)best, m, 64));
+        const int bk = (int)(best & 0xFFFF), minS = (int)(best >> 16) - 32768;
+        bool bad = false;
+        for (int k = lane; k < D; k += 64) bad |= ((int)sp[k] * (100 - a.uniq) < minS * 100) && (abs(bk - k) > 1);
+        if (__any(bad)) continue;
+        if (lane == 0) {
+            int d = bk;
+            const int x = x1 + a.minX1, x2 = x - d - a.minD;
+            atomicMin(&key[x2], ((best >> 16) << 16) | (u32)(0xFFFF - x));
+            if (d > 0 && d < D - 1) {
+                const int sm = sp[d - 1], s0 = sp[d], spl = sp[d + 1];
+                const int den = max(sm + spl - 2 * s0, 1);
+                d = d * 16 + ((sm - spl) * 16 + den) / (den * 2);
+            } else d *= 16;
+            d1[x] = (int16_t)(d + a.minD * 16);
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int v = d1[x];
+        if (v != INVALID && x >= a.minX1) {
+            auto inconsistent = [&](int xx, int dd) -> bool {
+                if (xx < 0 || xx >= W) return false;
+                const u32 kk = key[xx];
+                const int d2 = (kk == 0xFFFFFFFFu) ? INVALID : (0xFFFF - (int)(kk & 0xFFFF)) - xx;
+                return d2 >= a.minD && abs(d2 - dd) > a.maxDiff;
+            };
+            const int _d = v >> 4, d_ = (v + 15) >> 4;
+            if (inconsistent(x - _d, _d) && inconsistent(x - d_, d_)) v = INVALID;
+        }
+        a.disp[(size_t)y * W + x] = (int16_t)v;
+    }
+}
+
+// cv::medianBlur(src, dst, 3) on CV_16SC1: replicated borders
+__global__ __launch_bounds__(256) void median3_s16_kernel(const int16_t* __restrict__ src, int H, int W, int16_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int xs[3] = {x > 0 ? x - 1 : 0, x, x < W - 1 ? x + 1 : W - 1};
+    const int ys[3] = {y > 0 ? y - 1 : 0, y, y < H - 1 ? y + 1 : H - 1};
+    int v[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) v[i * 3 + j] = src[(size_t)ys[i] * W + xs[j]];
+    // median of nine by a fixed exchange network
+#define MD_SORT2(a, b) { const int lo__ = min(v[a], v[b]), hi__ = max(v[a], v[b]); v[a] = lo__; v[b] = hi__; }
+    MD_SORT2(1, 2) MD_SORT2(4, 5) MD_SORT2(7, 8) MD_SORT2(0, 1) MD_SORT2(3, 4) MD_SORT2(6, 7)
+    MD_SORT2(1, 2) MD_SORT2(4, 5) MD_SORT2(7, 8) MD_SORT2(0, 3) MD_SORT2(5, 8) MD_SORT2(4, 7)
+    MD_SORT2(3, 6) MD_SORT2(1, 4) MD_SORT2(2, 5) MD_SORT2(4, 7) MD_SORT2(4, 2) MD_SORT2(6, 4)
+    MD_SORT2(4, 2)
+#undef MD_SORT2
+    dst[(size_t)y * W + x] = (int16_t)v[4];
+}
+
+// ---- filterSpeckles: 4-connected regions of pixels != newVal whose neighbouring values differ by
+// at most maxDiff; regions of at most maxSize pixels become newVal.  Union-find over pixel indices.
+__device__ __forceinline__ int uf_find(const int* parent, int a)
+{
+    int p = __hip_atomic_load(parent + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != a) { a = p; p = __hip_atomic_load(parent + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return a;
+}
+__device__ __forceinline__ void uf_union(int* parent, int a, int b)
+{
+    for (int it = 0; it < (1 << 24); it++) {       // bounded; each round strictly lowers a root
+        a = uf_find(parent, a); b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(parent + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
+__global__ __launch_bounds__(256) void speckle_init_kernel(int* parent, int* count, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { parent[i] = i; count[i] = 0; }
+}
+__global__ __launch_bounds__(256) void speckle_link_kernel(const int16_t* __restrict__ img, int H, int W, int newVal, int maxDiff, int* parent)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int i = y * W + x, v = img[i];
+    if (v == newVal) return;
+    if (x + 1 < W) { const int q = img[i + 1]; if (q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, i + 1); }
+    if (y + 1 < H) { const int q = img[i + W]; if (q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, i + W); }
+}
+__global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __restrict__ img, int n, int newVal, int* parent, int* count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || img[i] == newVal) return;
+    const int r = uf_find(parent, i);
+    parent[i] = r;                       // every write moves a node closer to its root, so concurrent finds stay valid
+    atomicAdd(count + r, 1);
+}
+__global__ __launch_bounds__(256) void speckle_apply_kernel(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ parent,
+                                                            const int* __restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || img[i] == newVal) return;
+    if (count[uf_find(parent, i)] <= maxSize) img[i] = (int16_t)newVal;
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+int md_median3_s16(hipStream_t s, const int16_t* src, int H, int W, int16_t* dst)
+{
+    median3_s16_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(src, H, W, dst);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+size_t md_speckle_scratch_bytes(int H, int W) { return md_align((size_t)H * W * 4, 256) * 2; }
+
+int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal, int maxSize, int maxDiff, void* scratch)
+{
+    const int n = H * W;
+    int* parent = (int*)scratch;
+    int* count = (int*)((u8*)scratch + md_align((size_t)n * 4, 256));
+    speckle_init_kernel<<<nblk(n), 256, 0, s>>>(parent, count, n);
+    speckle_link_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(img, H, W, newVal, maxDiff, parent);
+    speckle_count_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, parent, count);
+    speckle_apply_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, maxSize, parent, count);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+size_t md_stereosgbm_bytes(int H, int W, int cn, const mdisp_stereosgbm_params* p)
+{
+    const int D = p->numDisparities, W1 = W - p->minDisparity - D;
+    const size_t N = (size_t)H * W, V = W1 > 0 ? (size_t)H * W1 * D : 0;
+    return md_align(N * 2 * cn, 256) * 2 + md_align(V * 2, 256) * 3 + md_align(V * 4, 256) + md_align(N * 2, 256) * 2 +
+           md_speckle_scratch_bytes(H, W) + 4096;
+}
+
+static int validate(int H, int W, int cn, const mdisp_stereosgbm_params* p)
+{
+    MD_REQUIRE(p, MDISP_E_BADARG, "null StereoSGBM parameters");
+    MD_REQUIRE(cn == 1 || cn == 3, MDISP_E_BADARG, "StereoSGBM takes 1- or 3-channel 8-bit images");
+    MD_REQUIRE(p->numDisparities > 0 && p->numDisparities % 16 == 0 && p->numDisparities <= 512, MDISP_E_BADARG,
+               "numDisparities must be a positive multiple of 16 (at most 512)");
+    MD_REQUIRE(p->minDisparity >= 0, MDISP_E_UNSUPPORTED, "negative minDisparity is not supported");
+    MD_REQUIRE(p->mode == MDISP_SGBM_MODE_SGBM || p->mode == MDISP_SGBM_MODE_HH, MDISP_E_UNSUPPORTED,
+               "StereoSGBM mode %d is not built (MODE_SGBM and MODE_HH are)", p->mode);
+    MD_REQUIRE((p->blockSize <= 0 || p->blockSize % 2 == 1) && p->blockSize <= 31, MDISP_E_BADARG, "blockSize must be odd (at most 31)");
+    MD_REQUIRE((size_t)H * W < ((size_t)1 << 30), MDISP_E_RANGE, "image too large");
+    return MDISP_OK;
+}
+
+// dL / dR: interleaved 8-bit images on the device; dDisp: H*W int16; ws: md_stereosgbm_bytes()
+int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int cn,
+                      const mdisp_stereosgbm_params* p, int16_t* dDisp, void* ws, int16_t* dCost, int16_t* dRaw)
+{
+    MD_TRY(validate(H, W, cn, p));
+    BtGeom g;
+    g.H = H; g.W = W; g.cn = cn; g.D = p->numDisparities; g.minD = p->minDisparity;
+    g.minX1 = g.minD + g.D; g.W1 = W - g.minX1; g.N = (size_t)H * W;
+    g.ftzero = (p->preFilterCap > 15 ? p->preFilterCap : 15) | 1;
+    g.bs = p->blockSize > 0 ? p->blockSize : 5;
+    const int P1 = p->P1 > 0 ? p->P1 : 2;
+    int P2 = p->P2 > 0 ? p->P2 : 5;
+    if (P2 < P1 + 1) P2 = P1 + 1;
+    const int INVALID = (g.minD - 1) * 16;
+    const size_t N = g.N, V = g.W1 > 0 ? (size_t)H * g.W1 * g.D : 0;
+    u8* base = (u8*)ws;
+    auto take = [&](size_t bytes) { u8* r = base; base += md_align(bytes, 256); return r; };
+    u8* pl1 = take(N * 2 * cn); u8* pl2 = take(N * 2 * cn);
+    int16_t* v0 = (int16_t*)take(V * 2); int16_t* v1 = (int16_t*)take(V * 2); int16_t* S = (int16_t*)take(V * 2);
+    int* acc = (int*)take(V * 4);
+    int16_t* raw = (int16_t*)take(N * 2); int16_t* med = (int16_t*)take(N * 2);
+    void* spk = take(md_speckle_scratch_bytes(H, W));
+    if (g.W1 <= 0) {
+        // every column is left of minDisparity + numDisparities: the library returns an all-invalid map
+        // (the median and speckle stages keep it constant)
+        SelArgs sa{};
+        sa.S = nullptr; sa.H = H; sa.W = W; sa.W1 = 0; sa.D = g.D; sa.minD = g.minD; sa.minX1 = W; sa.uniq = 0; sa.maxDiff = 1; sa.disp = dDisp;
+        bt_select_kernel<<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+        MD_HIP(hipGetLastError());
+        if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, dDisp, N * 2, hipMemcpyDeviceToDevice, s));
+        return MDISP_OK;
+    }
+    MD_REQUIRE((size_t)W * 6 + 16 <= 64 * 1024, MDISP_E_RANGE, "image wider than 10900 columns");
+    const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
+    bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
+    bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
+    bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
+    bt_window_kernel<false><<<gv, 256, 0, s>>>(v0, g, v1);
+    bt_window_kernel<true><<<gv, 256, 0, s>>>(v1, g, v0);          // v0 = block cost C
+    MD_HIP(hipGetLastError());
+    if (dCost) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
+    static const int DIRS[8][2] = {{+1, 0}, {+1, +1}, {0, +1}, {-1, +1}, {-1, 0}, {-1, -1}, {0, -1}, {+1, -1}};
+    PathArgs pa{v0, acc, H, g.W1, g.D, P1, P2};
+    const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
+    for (int grp = 0; grp < 2; grp++) {
+        const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
+        for (int i = 0; i < ndir; i++) {
+            const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
+            const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
+            const dim3 gp((nlines + 3) / 4);
+#define BT_PATH(NDV)                                                                        \
+            do {                                                                            \
+                if (i == 0) bt_path_kernel<NDV, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);  \
+                else bt_path_kernel<NDV, false><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
+            } while (0)
+            if (nd == 1) BT_PATH(1); else if (nd == 2) BT_PATH(2); else if (nd == 4) BT_PATH(4); else BT_PATH(8);
+#undef BT_PATH
+        }
+        bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
+    }
+    MD_HIP(hipGetLastError());
+    SelArgs sa;
+    sa.S = S; sa.H = H; sa.W = W; sa.W1 = g.W1; sa.D = g.D; sa.minD = g.minD; sa.minX1 = g.minX1;
+    sa.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    sa.maxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
+    sa.disp = raw;
+    bt_select_kernel<<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    MD_HIP(hipGetLastError());
+    if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, raw, N * 2, hipMemcpyDeviceToDevice, s));
+    const bool speckle = p->speckleWindowSize > 0;
+    MD_TRY(md_median3_s16(s, raw, H, W, speckle ? med : dDisp));
+    if (speckle) {
+        MD_TRY(md_filter_speckles_s16(s, med, H, W, INVALID, p->speckleWindowSize, 16 * p->speckleRange, spk));
+        MD_HIP(hipMemcpyAsync(dDisp, med, N * 2, hipMemcpyDeviceToDevice, s));
+    }
+    return MDISP_OK;
+}

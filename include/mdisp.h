@@ -118,6 +118,23 @@ typedef struct mdisp_sgbm_params {
     int censusMethod;       /* MDISP_BASIC_CENSUS / ROTATION_INVARIANT / UNIFORM                  */
 } mdisp_sgbm_params;
 
+/* Arguments of cv::StereoSGBM::create, in its order (methods/methods.cpp:1893: create(0, 48, 7);
+ * :1216-1219, :1565-1568: create(0,64,7,490,1960,1,63,10,100,32,MODE_SGBM)), for the entry points
+ * that run StereoSGBM with its own Birchfield-Tomasi block cost. */
+enum { MDISP_SGBM_MODE_SGBM = 0, MDISP_SGBM_MODE_HH = 1 };   /* StereoSGBM::MODE_SGBM (5 paths), MODE_HH (8 paths) */
+typedef struct mdisp_stereosgbm_params {
+    int minDisparity;       /* >= 0                                                                */
+    int numDisparities;     /* positive multiple of 16                                             */
+    int blockSize;          /* odd; <= 0 selects 5                                                 */
+    int P1, P2;             /* <= 0 select 2 and 5; P2 is raised to P1 + 1                         */
+    int disp12MaxDiff;      /* <= 0 selects 1                                                      */
+    int preFilterCap;       /* clip of the x-Sobel response: max(preFilterCap, 15) | 1             */
+    int uniquenessRatio;    /* < 0 selects 10                                                      */
+    int speckleWindowSize;  /* 0 disables the speckle filter                                       */
+    int speckleRange;
+    int mode;               /* MDISP_SGBM_MODE_*                                                   */
+} mdisp_stereosgbm_params;
+
 typedef struct mdisp_ctx mdisp_ctx;
 
 /* ---- library / context ---- */
@@ -176,6 +193,24 @@ int mdisp_sgbm(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdi
  * the path recursion can be checked value by value. */
 int mdisp_sgbm_volume(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, uint16_t* S);
 
+/* cv::StereoSGBM::create(...)->compute(left, right, disp) as called at methods/methods.cpp:1912, :1291,
+ * :1650: Birchfield-Tomasi block cost on the x-Sobel-prefiltered and raw images, MODE_SGBM / MODE_HH
+ * aggregation, uniqueness, x16 sub-pixel, disp12MaxDiff, then medianBlur(3) and filterSpeckles.
+ * left/right CV_8UC1 or CV_8UC3 of equal size; out CV_16S.  OpenCV itself is not part of the
+ * reference tree: the arithmetic is restated from its published algorithm and is not pinned by
+ * any fixture of the reference. */
+int mdisp_stereosgbm_compute(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right,
+                             const mdisp_stereosgbm_params* p, mdisp_image* out);
+/* Same, with the intermediate results a parity check wants: the block cost volume C as int16
+ * [rows][cols - minDisparity - numDisparities][numDisparities] (NULL to skip) and the disparity map
+ * before the median filter (CV_16S, NULL to skip).  No counterpart call in the reference. */
+int mdisp_stereosgbm_stages(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right,
+                            const mdisp_stereosgbm_params* p, mdisp_image* out, int16_t* cost, mdisp_image* raw);
+/* cv::medianBlur(src, dst, 3) on CV_16SC1 (the filter StereoSGBM::compute applies to its map). */
+int mdisp_median_blur3_s16(mdisp_ctx*, const mdisp_image* src, mdisp_image* dst);
+/* cv::filterSpeckles(img, newVal, maxSpeckleSize, maxDiff) on CV_16SC1, in place. */
+int mdisp_filter_speckles_s16(mdisp_ctx*, mdisp_image* img, int newVal, int maxSpeckleSize, int maxDiff);
+
 /* LR consistency check of PatchMatch::postProcess, methods/patchmatch.cpp:817-828.
  * dL/dR CV_32F, validL/validR CV_8U (1 = consistent within `thresh`). */
 int mdisp_lr_check(mdisp_ctx*, const mdisp_image* dL, const mdisp_image* dR, float thresh,
@@ -215,6 +250,12 @@ int mdisp_reproject_triangulate(mdisp_ctx*, const mdisp_image* disp, const doubl
 
 /* bytes of device workspace mdisp_sgbm_dev needs for one pair */
 size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p);
+
+/* cv::StereoSGBM::compute (see mdisp_stereosgbm_compute) on device-resident interleaved 8-bit images
+ * with `channels` = 1 or 3; d_disp: device int16 HxW; workspace as for mdisp_sgbm_dev. */
+size_t mdisp_stereosgbm_workspace_bytes(int rows, int cols, int channels, const mdisp_stereosgbm_params* p);
+int mdisp_stereosgbm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, int channels, size_t pitch,
+                         const mdisp_stereosgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
 
 /* d_left/d_right: device CV_8UC1 with the given pitch; d_disp: device int16 HxW (pitch = cols*2).
  * d_workspace: at least mdisp_sgbm_workspace_bytes() of device memory, or NULL to use the

@@ -68,6 +68,10 @@ inline cv::Mat getGuidedFilter_ours_gif3(cv::Mat guidedImg, cv::Mat inputP, int 
 { return mdisp::getGuidedFilter_ours_gif3(guidedImg, inputP, r, r2, eps, namuda, h, beta_); }
 inline void steerFilter(cv::Mat src, cv::Mat& dst) { mdisp::steerFilter(src, dst); }
 
+// cv::StereoSGBM::create(...)->compute(...) call sites (methods/methods.cpp:1216-1219, 1291, 1565-1568, 1650, 1893, 1912):
+// `mdisp_cv::StereoSGBM::create(0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, mdisp_cv::StereoSGBM::MODE_SGBM)->compute(l, r, d)`
+namespace mdisp_cv { typedef mdisp::StereoSGBMT<cv::Mat> StereoSGBM; }
+
 // methods/methods.h:33
 inline void getDisparity_SGBM(cv::Mat srcLeft, cv::Mat srcRight, cv::Mat& disparityMap) { mdisp::getDisparity_SGBM(srcLeft, srcRight, disparityMap); }
 

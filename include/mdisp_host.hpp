@@ -226,7 +226,7 @@ template <class M> void steerFilter(M src, M& dst)
     detail::check(mdisp_steer_filter(Context::forThisThread().handle(), &s, &d));
 }
 
-// cv::StereoSGBM::compute stand-in -> CV_16S x16 (the census-Hamming cost replaces Birchfield-Tomasi)
+// SGM with the reference-owned census-Hamming cost (StereoSGBM's recursion and selection rules) -> CV_16S x16
 template <class M> void sgbmCompute(M left, M right, const mdisp_sgbm_params& p, M& disp16)
 {
     typedef mat_traits<M> T;
@@ -236,14 +236,40 @@ template <class M> void sgbmCompute(M left, M right, const mdisp_sgbm_params& p,
     detail::check(mdisp_sgbm(Context::forThisThread().handle(), &l, &r, &p, &d));
 }
 
+// cv::StereoSGBM as the reference uses it (methods/methods.cpp:1216-1219, 1291, 1893, 1912): create() with the
+// library's argument order and defaults, compute() -> CV_16S x16.  Birchfield-Tomasi block cost, MODE_SGBM / MODE_HH.
+template <class M> class StereoSGBMT {
+public:
+    enum { MODE_SGBM = MDISP_SGBM_MODE_SGBM, MODE_HH = MDISP_SGBM_MODE_HH };
+    static StereoSGBMT create(int minDisparity = 0, int numDisparities = 16, int blockSize = 3, int P1 = 0, int P2 = 0,
+                              int disp12MaxDiff = 0, int preFilterCap = 0, int uniquenessRatio = 0, int speckleWindowSize = 0,
+                              int speckleRange = 0, int mode = MODE_SGBM)
+    {
+        StereoSGBMT s;
+        const mdisp_stereosgbm_params p = {minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap,
+                                           uniquenessRatio, speckleWindowSize, speckleRange, mode};
+        s.params = p;
+        return s;
+    }
+    StereoSGBMT* operator->() { return this; }          // so that `create(...)->compute(...)` reads as with cv::Ptr
+    void compute(M left, M right, M& disparity) const
+    {
+        typedef mat_traits<M> T;
+        mdisp_image l = T::view(left), r = T::view(right);
+        T::create(disparity, l.rows, l.cols, MDISP_16S, 1);
+        mdisp_image d = T::view(disparity);
+        detail::check(mdisp_stereosgbm_compute(Context::forThisThread().handle(), &l, &r, &params, &d));
+    }
+    mdisp_stereosgbm_params params;
+};
+
 // methods/methods.h:33, methods.cpp:1883-1921: StereoSGBM::create(0, 48, 7), compute, disp / 16
 // (CV_16S MatExpr divide: round to nearest, ties to even)
 template <class M> void getDisparity_SGBM(M srcLeft, M srcRight, M& disparityMap)
 {
     typedef mat_traits<M> T;
     if (T::empty(srcLeft) || T::empty(srcRight)) { std::cout << " --(!) Error reading images " << std::endl; return; }
-    mdisp_sgbm_params p = {0, 48, 0, 0, -1, 0, 5, 1, 1, MDISP_BASIC_CENSUS};
-    sgbmCompute(srcLeft, srcRight, p, disparityMap);
+    StereoSGBMT<M>::create(0, 48, 7).compute(srcLeft, srcRight, disparityMap);
     mdisp_image d = T::view(disparityMap);
     for (int y = 0; y < d.rows; y++) {
         int16_t* row = reinterpret_cast<int16_t*>(static_cast<uint8_t*>(d.data) + d.step_bytes * (size_t)y);
@@ -299,6 +325,7 @@ template <class M> void reprojectTriangulate(M disparityMap, const double K_new[
 }
 
 typedef StereoMatchParamT<Mat> StereoMatchParam;
+typedef StereoSGBMT<Mat> StereoSGBM;
 
 }  // namespace mdisp
 #endif  // MDISP_HOST_HPP

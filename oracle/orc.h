@@ -61,6 +61,13 @@ typedef struct {
     int censusMethod;
 } orc_sgm_params;
 
+/* cv::StereoSGBM parameters (create() argument order) */
+enum { ORC_SGBM_MODE_SGBM = 0, ORC_SGBM_MODE_HH = 1 };
+typedef struct {
+    int minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+        speckleWindowSize, speckleRange, mode;
+} orc_sgbm_bt_params;
+
 /* ---- borders / colour ---- */
 int  orc_reflect(int p, int n);        /* BORDER_REFLECT     fedcba|abcdef|fedcba */
 int  orc_reflect101(int p, int n);     /* BORDER_REFLECT_101 gfedcb|abcdef|edcba  */
@@ -109,6 +116,12 @@ int  orc_asw_gifs(const uint8_t* guide, const float* costs /*D*H*W f32*/, int H,
 /* ---- SGM ---- */
 int orc_sgm(const uint8_t* L, const uint8_t* R, int H, int W, const orc_sgm_params* p,
             int16_t* disp, uint16_t* Svol /*nullable: H*W*D*/);
+
+/* cv::StereoSGBM::compute with its own Birchfield-Tomasi block cost (parity unpinned), cn = 1 or 3 */
+int orc_sgbm_bt(const uint8_t* L, const uint8_t* R, int H, int W, int cn, const orc_sgbm_bt_params* p, int16_t* disp,
+                int16_t* Cvol /* nullable */, int16_t* raw /* nullable */);
+void orc_median3_s16(const int16_t* src, int H, int W, int16_t* dst);
+void orc_filter_speckles_s16(int16_t* img, int H, int W, int newVal, int maxSpeckleSize, int maxDiff);
 
 /* ---- LR check (patchmatch.cpp:817-828) ---- */
 void orc_lr_check(const float* dL, const float* dR, int H, int W, float thresh, uint8_t* validL, uint8_t* validR);

@@ -25,6 +25,14 @@ class orc_sgm_params(C.Structure):
                 ("costWin", C.c_int), ("censusMethod", C.c_int)]
 
 
+class orc_sgbm_bt_params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("minDisparity", "numDisparities", "blockSize", "P1", "P2", "disp12MaxDiff", "preFilterCap",
+                                       "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
+
+
+MODE_SGBM, MODE_HH = 0, 1
+
+
 def build(force=False):
     srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
@@ -307,3 +315,40 @@ def reproject_triangulate(disp, K, baseline, bgr=None):
     c = np.ascontiguousarray(bgr, np.float32) if bgr is not None else None
     fn(_p(disp), H, W, _p(K), float(baseline), _p(c) if c is not None else None, _p(xyz))
     return xyz
+
+
+def sgbm_bt(L, R, minDisparity=0, numDisparities=16, blockSize=3, P1=0, P2=0, disp12MaxDiff=0, preFilterCap=0,
+            uniquenessRatio=0, speckleWindowSize=0, speckleRange=0, mode=MODE_SGBM, want_cost=False, want_raw=False):
+    """cv::StereoSGBM::create(...)->compute(L, R) restated (parity unpinned); images HxW or HxWx3 uint8."""
+    L, R = np.ascontiguousarray(L, np.uint8), np.ascontiguousarray(R, np.uint8)
+    H, W = L.shape[:2]
+    cn = 1 if L.ndim == 2 else L.shape[2]
+    p = orc_sgbm_bt_params(minDisparity, numDisparities, blockSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+                           speckleWindowSize, speckleRange, mode)
+    disp = np.empty((H, W), np.int16)
+    W1 = max(W - minDisparity - numDisparities, 0)
+    cost = np.empty((H, W1, numDisparities), np.int16) if want_cost else None
+    raw = np.empty((H, W), np.int16) if want_raw else None
+    rc = lib().orc_sgbm_bt(_p(L), _p(R), H, W, cn, C.byref(p), _p(disp), _p(cost) if want_cost else None,
+                           _p(raw) if want_raw else None)
+    if rc:
+        raise ValueError(f"orc_sgbm_bt rc={rc}")
+    out = [disp]
+    if want_cost:
+        out.append(cost)
+    if want_raw:
+        out.append(raw)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def median3_s16(src):
+    src = np.ascontiguousarray(src, np.int16)
+    dst = np.empty_like(src)
+    lib().orc_median3_s16(_p(src), src.shape[0], src.shape[1], _p(dst))
+    return dst
+
+
+def filter_speckles_s16(img, newVal, maxSpeckleSize, maxDiff):
+    out = np.ascontiguousarray(img, np.int16).copy()
+    lib().orc_filter_speckles_s16(_p(out), out.shape[0], out.shape[1], newVal, maxSpeckleSize, maxDiff)
+    return out

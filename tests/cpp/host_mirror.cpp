@@ -53,6 +53,12 @@ int main(int argc, char** argv)
     std::fwrite(d16.data(), 2, (size_t)H * W, f);
     std::fwrite(cen.data(), 1, (size_t)H * W, f);
     std::fwrite(dOurs.data(), 4, (size_t)H * W, f);
+    Mat dBt, dG;
+    StereoSGBM::create(0, 32, 7, 490, 1960, 1, 63, 10, 100, 32, StereoSGBM::MODE_SGBM)->compute(L, R, dBt);   // methods.cpp:1216-1219 shape
+    getDisparity_SGBM(L, R, dG);                                                                              // methods.cpp:1883-1921
+    if (dBt.empty() || dG.empty()) return fail("empty StereoSGBM output");
+    std::fwrite(dBt.data(), 2, (size_t)H * W, f);
+    std::fwrite(dG.data(), 2, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

@@ -50,7 +50,11 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     dS = buf[o:o + n].reshape(H, W); o += n
     d16 = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
     cen = buf[o:o + n].reshape(H, W); o += n
-    dO = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
+    dO = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    dBt = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
+    dG = buf[o:o + 2 * n].view(np.int16).reshape(H, W)
+    assert np.array_equal(dBt, orc.sgbm_bt(L, R, 0, 32, 7, 490, 1960, 1, 63, 10, 100, 32, orc.MODE_SGBM))
+    assert np.array_equal(dG, np.rint(orc.sgbm_bt(L, R, 0, 48, 7).astype(np.float64) / 16.0).astype(np.int16))
     assert np.array_equal(dC, orc.census_stereo(L, R, 7, 0, maxD, True, orc.BASIC_CENSUS, orc.AGG_BOX))
     assert np.array_equal(dS, orc.sad_box(L, R, 7, 0, maxD, True))
     assert np.array_equal(d16, orc.sgm(L, R, 0, maxD + 1, 8, 32, 10, 1, 8, 1))

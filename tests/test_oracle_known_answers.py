@@ -267,3 +267,61 @@ def test_reprojection_known_answers(orc):
     K = np.array([[500.0, 0, 3.0], [0, 500.0, 2.0], [0, 0, 1.0]])
     p = orc.reproject_triangulate(disp, K, 100.0)[2, 3]
     assert np.allclose(p, [0.0, 0.0, 100.0 * 500.0 / 8.0], rtol=1e-6)
+
+
+def test_bilateral_restatement_against_direct_formula(orc):
+    # cv::bilateralFilter restated with its 4096-bin colour table: within 1e-5 of the closed-form
+    # weights exp(-r^2/2ss^2) * exp(-dv^2/2sc^2) over the circular footprint; flat images are copied
+    rng = np.random.default_rng(0)
+    a = (rng.random((20, 30)) * 3).astype(np.float32)
+    got = orc.bilateral_filter(a, 5, 2, 3)
+    H, W = a.shape
+    R = 2
+    pad = np.pad(a, R, mode="reflect")
+    exp = np.zeros_like(a)
+    for y in range(H):
+        for x in range(W):
+            s = ws = 0.0
+            for i in range(-R, R + 1):
+                for j in range(-R, R + 1):
+                    if (i * i + j * j) ** 0.5 > R:
+                        continue
+                    v = float(pad[y + R + i, x + R + j])
+                    w = np.exp(-(i * i + j * j) / 18.0) * np.exp(-((v - float(a[y, x])) ** 2) / 8.0)
+                    s += v * w
+                    ws += w
+            exp[y, x] = s / ws
+    assert np.abs(got - exp).max() < 1e-5
+    flat = np.full((9, 11), 0.25, np.float32)
+    assert np.array_equal(orc.bilateral_filter(flat, 7, 2, 3), flat)
+
+
+def test_stereosgbm_restatement_known_answers(orc):
+    # identical images: every block cost at d = 0 is zero, so the winner is 0 wherever the range is computed;
+    # columns left of minDisparity + numDisparities are invalid ((minD - 1) * 16)
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (24, 80)).astype(np.uint8)
+    d, cost = orc.sgbm_bt(img, img, 0, 16, 5, want_cost=True)
+    assert (cost[:, :, 0] == 0).all()
+    assert (d[:, :16] == -16).all()
+    assert (d[:, 16:] == 0).all()
+    # a pure shift by 5 columns is found exactly away from the borders
+    R = rng.integers(0, 256, (24, 120)).astype(np.uint8)
+    L = np.roll(R, 5, axis=1)
+    d = orc.sgbm_bt(L, R, 0, 16, 5)
+    assert (np.abs(d[2:-2, 24:-8] - 5 * 16) < 8).all()           # within the sub-pixel parabola's half step
+    # a range wider than the image leaves nothing to compute
+    assert (orc.sgbm_bt(img[:, :30], img[:, :30], 0, 32, 5) == -16).all()
+
+
+def test_median_and_speckle_restatements(orc):
+    a = np.arange(30, dtype=np.int16).reshape(5, 6)
+    m = orc.median3_s16(a)
+    assert m[2, 2] == a[2, 2] and m[0, 0] == a[0, 1]          # replicated borders: {0,0,1,0,0,1,6,6,7} -> 1
+    img = np.full((8, 8), 160, np.int16)
+    img[2:4, 2:4] = 800                                        # a 4-pixel island
+    img[6, 6] = -16                                            # already invalid
+    out = orc.filter_speckles_s16(img, -16, 4, 16)
+    assert (out[2:4, 2:4] == -16).all() and out[0, 0] == 160 and out[6, 6] == -16
+    assert np.array_equal(orc.filter_speckles_s16(img, -16, 3, 16), img)
+    assert (orc.filter_speckles_s16(img, -16, 4, 1000) == img).all()    # one big region when everything connects
