@@ -66,3 +66,26 @@ p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=35, minDisparity=0, maxD
 for name, gif in (("GIF", api.GIF), ("SKWGIF", api.SKWGIF)):
     dt, r = host_rate(lambda: api.asw_gifs(p, 0.01, gif, 15, 0.1, 0.5, api.COST_CENSUS), H, W, D, n=2)
     print(f"asw_gifs {name:7s} win 35 r2 15 {W}x{H} D={D} host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")
+
+# cv::StereoSGBM replacement (Birchfield-Tomasi block cost), device-resident
+import ctypes as C
+from cameracalibration_amd import _lib
+lib = _lib.load()
+for (H, W, args) in ((480, 640, (0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, 0)), (1080, 1920, (0, 256, 7, 490, 1960, 1, 63, 10, 100, 32, 0)),
+                     (1080, 1920, (0, 256, 7, 490, 1960, 1, 63, 10, 100, 32, 1))):
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, args[1])
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    p = api.StereoSGBM_create(*args)
+    ctx = _lib.Context(stream=torch.cuda.current_stream().cuda_stream)
+    nb = lib.mdisp_stereosgbm_workspace_bytes(H, W, 1, C.byref(p))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    def run():
+        _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), H, W, 1, W, C.byref(p), out.data_ptr(), ws.data_ptr(), nb))
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"StereoSGBM (BT, block 7, mode {args[-1]}) {W}x{H} D={args[1]} device-resident: {dt*1e3:.2f} ms  {H*W*args[1]/dt/1e6:.0f} Mdisp/s")
