@@ -101,6 +101,22 @@ template <> struct CVec<8> { typedef uint4 type; };
 
 struct PathArgs { const int16_t* C; int* acc; int H, W1, D, P1, P2; };
 
+// cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
+__device__ __forceinline__ int wave_shr1(int v, int fill)      // lane i <- lane i-1, lane 0 <- fill
+{ return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_shl1(int v, int fill)      // lane i <- lane i+1, lane 63 <- fill
+{ return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_min_dpp(int v)
+{
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));    // row_mirror: every lane holds its row's minimum
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 template <int ND, bool FIRST>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
@@ -126,19 +142,35 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     int minPrev = 0;
     const int P1 = a.P1, P2 = a.P2;
     typedef typename CVec<ND>::type V;
-    V cnext = V();
-    auto fetch = [&](int t) {
-        if (mine) cnext = *reinterpret_cast<const V*>(a.C + ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0);
+    // operands of step t + PF are requested when step t retires, so PF cost rows (and accumulator rows)
+    // are in flight per wave while the serial recursion runs
+    constexpr int PF = ND <= 2 ? 16 : 8;
+    struct In { V c; int old[ND]; };
+    In ring[PF];
+    auto fetch = [&](int t, In& in) {
+        if (!mine) return;
+        const size_t o = ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
+        in.c = *reinterpret_cast<const V*>(a.C + o);
+        if (!FIRST) {
+#pragma unroll
+            for (int j = 0; j < ND; j++) in.old[j] = a.acc[o + j];
+        }
     };
-    fetch(0);
-    for (int t = 0; t < n; t++) {
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        if (u < n) fetch(u, ring[u]);
+    for (int t0 = 0; t0 < n; t0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+        const int t = t0 + u;
+        if (t >= n) break;
         int16_t c[ND];
-        __builtin_memcpy(c, &cnext, sizeof(V));
-        if (t + 1 < n) fetch(t + 1);
-        int left = __shfl_up(Lp[ND - 1], 1, 64);
-        int right = __shfl_down(Lp[0], 1, 64);
-        if (lane == 0) left = 32767;
-        if (lane == 63) right = 32767;
+        int old[ND];
+        __builtin_memcpy(c, &ring[u].c, sizeof(V));
+#pragma unroll
+        for (int j = 0; j < ND; j++) old[j] = FIRST ? 0 : ring[u].old[j];
+        const int left = wave_shr1(Lp[ND - 1], 32767);
+        const int right = wave_shl1(Lp[0], 32767);
         const int delta = minPrev + P2;
         int Ln[ND], mn = BT_BIG;
 #pragma unroll
@@ -150,16 +182,17 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
             Ln[j] = L;
             mn = min(mn, L);
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mn = min(mn, __shfl_xor(mn, m, 64));
+        mn = wave_min_dpp(mn);
         if (mine) {
             int* ap = a.acc + ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
 #pragma unroll
-            for (int j = 0; j < ND; j++) ap[j] = FIRST ? Ln[j] : ap[j] + Ln[j];
+            for (int j = 0; j < ND; j++) ap[j] = old[j] + Ln[j];
         }
 #pragma unroll
         for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
         minPrev = mn;
+        if (t + PF < n) fetch(t + PF, ring[u]);
+    }
     }
 }
 
@@ -286,10 +319,21 @@ __global__ __launch_bounds__(256) void speckle_link_kernel(const int16_t* __rest
 __global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __restrict__ img, int n, int newVal, int* parent, int* count)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || img[i] == newVal) return;
-    const int r = uf_find(parent, i);
-    parent[i] = r;                       // every write moves a node closer to its root, so concurrent finds stay valid
-    atomicAdd(count + r, 1);
+    int r = -1;
+    if (i < n && img[i] != newVal) {
+        r = uf_find(parent, i);
+        parent[i] = r;                   // every write moves a node closer to its root, so concurrent finds stay valid
+    }
+    // consecutive pixels mostly share a root: one atomic per run of equal roots inside the wave
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(r, 1, 64);
+    const bool head = lane == 0 || prev != r;
+    const unsigned long long heads = __ballot(head);
+    if (head && r >= 0) {
+        const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = after ? __ffsll((long long)after) : 64 - lane;
+        atomicAdd(count + r, len);
+    }
 }
 __global__ __launch_bounds__(256) void speckle_apply_kernel(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ parent,
                                                             const int* __restrict__ count)
