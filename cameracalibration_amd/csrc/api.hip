@@ -39,7 +39,7 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_failed = false; c->stage = nullptr; c->stage_bytes = 0;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_failed = false; c->aux = nullptr; c->aux_ready = false; c->stage = nullptr; c->stage_bytes = 0;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -61,6 +61,11 @@ extern "C" void mdisp_destroy(mdisp_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
     for (int i = 0; i < 6; i++) (void)hipEventDestroy(c->ev[i]);
+    if (c->aux_ready) {
+        (void)hipStreamSynchronize(c->aux);
+        for (int i = 0; i < 3; i++) (void)hipEventDestroy(c->aux_ev[i]);
+        (void)hipStreamDestroy(c->aux);
+    }
     if (c->stage) (void)hipFree(c->stage);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -71,6 +76,18 @@ extern "C" int mdisp_synchronize(mdisp_ctx* c)
     MD_REQUIRE(c, MDISP_E_BADARG, "null context");
     MD_HIP(hipStreamSynchronize(c->stream));
     return md_check_sgm_error(c);
+}
+
+int md_ctx_aux(mdisp_ctx* c, md_aux_streams* out)
+{
+    if (!c->aux_ready) {
+        MD_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++) MD_HIP(hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming));
+        c->aux_ready = true;
+    }
+    out->aux = c->aux;
+    for (int i = 0; i < 3; i++) out->ev[i] = c->aux_ev[i];
+    return MDISP_OK;
 }
 
 int md_check_sgm_error(mdisp_ctx* c)

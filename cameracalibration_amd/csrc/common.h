@@ -47,6 +47,9 @@ struct mdisp_ctx {
     bool ev_valid[3];
     void* stage;         // grow-only device staging buffer of the host<->device image copies
     size_t stage_bytes;
+    hipStream_t aux;     // second stream for independent SGM stages of small batches (created on first use)
+    hipEvent_t aux_ev[3];
+    bool aux_ready;
     const int* sgm_err;  // device error word of the last pipelined SGM call (0 = fine), or null
     bool sgm_failed;     // an error word was set when it had to be read early (workspace about to be released)
 };
@@ -86,13 +89,18 @@ struct md_sgm_plan {
     bool use_v2;      // strip-fused two-sweep aggregation (sgm2.hip) instead of per-direction scans
     int sstride;      // u16 elements per pixel in the S volume
 };
+// second stream + fork/join events of a context (created on first use); null members = run everything on one stream
+struct md_aux_streams { hipStream_t aux; hipEvent_t ev[3]; };
+int md_ctx_aux(mdisp_ctx* ctx, md_aux_streams* out);
+
 // sgm2.hip
 bool md_sgm2_supported(const md_sgm_plan& pl);
 size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch);
 int md_sgm2_slots(const md_sgm_plan& pl);   // u16 elements per pixel of the S volume (64, 128 or 256)
 bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord);
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord,
+                      const md_aux_streams* aux = nullptr);
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
                int16_t* dDisp, void* ws);

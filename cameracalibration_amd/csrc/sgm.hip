@@ -331,8 +331,10 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
     }
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
     if (pl.use_v2) {
+        md_aux_streams aux;
+        const bool haveAux = md_ctx_aux(ctx, &aux) == MDISP_OK;
         rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch,
-                               dDisp ? 0 : 1, dDisp, &ctx->sgm_err);
+                               dDisp ? 0 : 1, dDisp, &ctx->sgm_err, haveAux ? &aux : nullptr);
         if (rc) return rc;
     } else {
         for (int i = 0; i < pl.batch; i++) {

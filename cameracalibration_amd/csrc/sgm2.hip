@@ -73,6 +73,7 @@ struct Sgm2Args {
     int tail;                             // 1 when D < 256: disparities >= D are masked off
     int naturalOut;                       // last sweep: store the full sum in natural d order (volume export)
     int five;                             // 5-path mode (both horizontals + the three downward paths): the down sweep is the last one
+    u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
     uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
     int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
 };
@@ -397,7 +398,8 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     const int cw = min(CW, W - x0);
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
-    u16* Sp = a.S + (size_t)pair * a.strideS;
+    const bool readS = UP && !a.splitUp;
+    u16* Sp = (UP && a.splitUp ? a.S2 : a.S) + (size_t)pair * a.strideS;
     const u8* Hp = a.Hvol[UP ? 1 : 0] + (size_t)pair * a.strideH;
     const u16* bA = a.bnd[UP ? 2 : 0] + (size_t)pair * a.strideB;   // diagonal with dx = +1 (predecessor at x-1)
     const u16* bB = a.bnd[UP ? 3 : 1] + (size_t)pair * a.strideB;   // diagonal with dx = -1 (predecessor at x+1)
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
         const size_t pix = (size_t)y * W + x;
         if (U8) hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
         else load8(reinterpret_cast<const u16*>(Hp + pix * 512) + lic * DPL, Hnext);
-        if (UP) load8(Sp + (pix * 256 + lic * DPL), Snext);
+        if (readS) load8(Sp + (pix * 256 + lic * DPL), Snext);
         if (r > 0) {
             if (edgeA) load8(bA + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnA);
             if (edgeB) load8(bB + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnB);
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
             }
 #pragma unroll
             for (int q = 0; q < NR; q++) {
-                if (UP) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+                if (readS) Sacc[q] = pkadd(Sacc[q], Snext[q]);
                 NA[q] = BnA[q]; NB[q] = BnB[q];
             }
             if (r + 1 < H) fetch_row(r + 1);
@@ -789,6 +791,36 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     }
 }
 
+// Split mode (small batches): the down and the up sweep run side by side on two streams and each
+// stores its four-path sum (register order); this kernel adds the two and runs the winner-take-all.
+// One workgroup per image row.
+template <bool TAIL>
+__global__ __launch_bounds__(256) void sgm2_wta_sum_kernel(Sgm2Args a)
+{
+    __shared__ u32 srow[CW][128];
+    __shared__ u32 exclMask[19][NR];
+    init_excl_mask(exclMask);
+    __syncthreads();
+    const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
+    const int y = blockIdx.x, pair = blockIdx.y, W = a.W;
+    const u16* Sa = a.S + (size_t)pair * a.strideS;
+    const u16* Sb = a.S2 + (size_t)pair * a.strideS;
+    u32 tail[NR];
+    make_tail(lic, a.D, tail);
+    for (int x0 = 0; x0 < W; x0 += CW) {
+        const int x = x0 + lr;
+        if (x < W) {
+            const size_t pix = (size_t)y * W + x;
+            u32 A[NR], B[NR];
+            load8_stream(Sa + (pix * 256 + lic * DPL), A);
+            load8_stream(Sb + (pix * 256 + lic * DPL), B);
+#pragma unroll
+            for (int q = 0; q < NR; q++) A[q] = pkadd(A[q], B[q]);
+            fused_wta<TAIL>(a, A, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
+        }
+    }
+}
+
 struct LrArgs {
     const uint2* rec; size_t strideRec;
     int H, W, D, minD, maxDiff, subpixel;
@@ -850,13 +882,29 @@ __global__ __launch_bounds__(256) void sgm2_lr_kernel(LrArgs a)
 
 static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin + pl.P2 <= 255; }
 
-// the pipelined sheared sweeps replace the border pre-pass whenever path values fit a byte
-static bool use_shear(bool u8mode) { return u8mode && !getenv("MDISP_SGM_PREPASS"); }
+// How the eight (five) paths are scheduled:
+//   SHEAR    pipelined sheared sweeps (byte path states): the throughput mode for batches
+//   PREPASS  upright strips + diagonal pre-pass, one sweep after the other (16-bit path states, or on request)
+//   SPLIT    upright strips, the two sweeps side by side on two streams and a summing winner-take-all: a batch of
+//            a few pairs cannot fill the strip pipeline, so the latency of one pair counts
+enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2 };
+static int split_max_batch()
+{
+    const char* e = getenv("MDISP_SGM_SPLIT_MAX");
+    return e ? atoi(e) : 4;
+}
+static int sgm2_mode(const md_sgm_plan& pl)
+{
+    if (!fits_u8(pl)) return SGM2_PREPASS;
+    if (getenv("MDISP_SGM_PREPASS")) return SGM2_PREPASS;
+    if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
+    return SGM2_SHEAR;
+}
 
 // lanes per pixel: the sheared kernels run 64 / 128 / 256 disparity slots per pixel, the others always 256
 static int lanes_per_pixel(const md_sgm_plan& pl)
 {
-    if (!use_shear(fits_u8(pl)) || getenv("MDISP_SGM_LANES16")) return 16;
+    if (sgm2_mode(pl) != SGM2_SHEAR || getenv("MDISP_SGM_LANES16")) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
 int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
@@ -866,18 +914,20 @@ static size_t shear_hand_bytes(int H, int W, int lpc) { return md_align((size_t)
 static size_t shear_sync_bytes(int H, int W, int batch, int lpc)
 { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, 256 / lpc)) * sizeof(int), 256); }
 
-struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, syncBytes; int nstrips, lpc, slots; bool u8m; };
+struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, slots, mode; bool u8m; };
 static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
 {
     Sgm2Layout l;
     l.u8m = fits_u8(pl);
+    l.mode = sgm2_mode(pl);
     l.lpc = lanes_per_pixel(pl);
     l.slots = l.lpc * DPL;
     l.nstrips = (pl.W + CW - 1) / CW;
-    if (use_shear(l.u8m)) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc); }   // hand-off rows
+    if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc); }   // hand-off rows
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
+    l.oneS2 = l.mode == SGM2_SPLIT ? md_align((size_t)pl.H * pl.W * 256 * sizeof(u16), 256) : 0;
     l.syncBytes = shear_sync_bytes(pl.H, pl.W, batch, l.lpc);
     return l;
 }
@@ -885,7 +935,7 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
 size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
 {
     const Sgm2Layout l = sgm2_layout(pl, batch);
-    return (l.bndBytes + 2 * l.oneH + l.oneRec) * batch + l.syncBytes;
+    return (l.bndBytes + 2 * l.oneH + l.oneRec + l.oneS2) * batch + l.syncBytes;
 }
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
@@ -929,7 +979,8 @@ int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int 
 // naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
 // naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord)
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord,
+                      const md_aux_streams* aux)
 {
     Sgm2Args a;
     if (errWord) *errWord = nullptr;
@@ -953,11 +1004,35 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.rec = (uint2*)(hbase + 2 * l.oneH * batch);
     a.strideRec = l.oneRec / sizeof(uint2);
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
-    if (use_shear(u8m)) {
+    a.S2 = nullptr; a.splitUp = 0;
+    u8* afterRec = hbase + 2 * l.oneH * batch + l.oneRec * batch;
+    if (l.mode == SGM2_SPLIT && !naturalOut && strideS * sizeof(u16) == l.oneS2) {
+        // hscan || prepass, then down sweep || up sweep, then the summing winner-take-all
+        a.S2 = (u16*)afterRec; a.splitUp = 1;
+        hipStream_t s2 = aux ? aux->aux : s;
+        dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
+        if (aux) { MD_HIP(hipEventRecord(aux->ev[0], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[0], 0)); }
+#define SGM2_SPLIT_LAUNCH(TAILV)                                                                 \
+        do {                                                                                     \
+            sgm2_hscan_kernel<TAILV, true, 16><<<gh, 256, 0, s>>>(a);                            \
+            sgm2_prepass_kernel<TAILV><<<gp, 256, 0, s2>>>(a);                                   \
+            if (aux) {                                                                           \
+                MD_HIP(hipEventRecord(aux->ev[1], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[1], 0));   \
+                MD_HIP(hipEventRecord(aux->ev[2], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[2], 0));   \
+            }                                                                                    \
+            sgm2_sweep_kernel<false, TAILV, true, false><<<gs, 256, 0, s>>>(a);                  \
+            sgm2_sweep_kernel<true, TAILV, true, false><<<gs, 256, 0, s2>>>(a);                  \
+            if (aux) { MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0)); }  \
+            sgm2_wta_sum_kernel<TAILV><<<dim3(pl.H, batch), 256, 0, s>>>(a);                     \
+        } while (0)
+        if (a.tail) SGM2_SPLIT_LAUNCH(true); else SGM2_SPLIT_LAUNCH(false);
+#undef SGM2_SPLIT_LAUNCH
+        MD_HIP(hipGetLastError());
+    } else if (l.mode == SGM2_SHEAR) {
         ShearArgs sa;
         sa.a = a;
         sa.hand = extra; sa.strideHand = l.bndBytes;
-        sa.sync = (int*)(hbase + 2 * l.oneH * batch + l.oneRec * batch);
+        sa.sync = (int*)afterRec;
         sa.nsh = shear_strips(pl.H, pl.W, 256 / l.lpc); sa.cmin = -(pl.H - 1); sa.batch = batch;
         MD_HIP(hipMemsetAsync(sa.sync, 0, l.syncBytes, s));
         if (errWord) *errWord = sa.sync + 2;

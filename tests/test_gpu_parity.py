@@ -159,8 +159,19 @@ SGM_CASES = [
 ]
 
 
+# how a single pair is scheduled: "latency" = the default for small batches (two sweeps side by side on two
+# streams + summing winner-take-all), "pipeline" = the sheared strip pipeline that batches use
+@pytest.fixture(params=["latency", "pipeline"])
+def sgm_schedule(request, monkeypatch):
+    if request.param == "pipeline":
+        monkeypatch.setenv("MDISP_SGM_SPLIT_MAX", "0")
+    else:
+        monkeypatch.delenv("MDISP_SGM_SPLIT_MAX", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("case", SGM_CASES)
-def test_sgm_bit_exact(api, orc, case):
+def test_sgm_bit_exact(api, orc, case, sgm_schedule):
     H, W, minD, D, P1, P2, uniq, maxDiff, paths, sub = case
     L, R = rand_pair(H * 31 + W, H, W, min(D, W))
     got = api.sgbm_compute(L, R, api.sgbm_params(minD, D, P1, P2, uniq, maxDiff, paths, sub))
@@ -221,13 +232,14 @@ def test_remap_fixed_point(api, orc):
         assert np.array_equal(api.remap(img, m1, m2), orc.remap(img, m1, m2))
 
 
-def test_sgm_batch_matches_single_calls(api, orc):
-    """mdisp_sgbm_batch_dev over 3 pairs == 3 single host calls (and the oracle)."""
+@pytest.mark.parametrize("B", [3, 6])        # a small batch (latency schedule) and one the strip pipeline takes
+def test_sgm_batch_matches_single_calls(api, orc, B):
+    """mdisp_sgbm_batch_dev over B pairs == the oracle on every pair."""
     import ctypes as C
     import torch
     from cameracalibration_amd import _lib
     lib = _lib.load()
-    H, W, D, B = 40, 72, 96, 3
+    H, W, D = 40, 72, 96
     params = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
     Ls, Rs = [], []
     for i in range(B):
@@ -259,7 +271,7 @@ def test_sgm_volume_bit_exact(api, orc):
 
 
 @pytest.mark.gpu
-def test_sgm_full_size_frame_bit_exact(api, orc):
+def test_sgm_full_size_frame_bit_exact(api, orc, sgm_schedule):
     # the benchmark configuration itself: 1920x1080, D = 256, P1 = 8, P2 = 32, 8 paths (oracle: about a second)
     L, R, gt = api.synth_pair(0x5EED0001, 1080, 1920, 256)
     p = api.sgbm_params(0, 256, 8, 32, 10, 1, 8, 1)
