@@ -572,7 +572,7 @@ __device__ __forceinline__ uint4 hand_load(const u8* p)
     return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
-template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC>
+template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, bool FIVE = false>
 __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
 {
     // LPC lanes share a pixel (16 disparities each); a strip is CW = 256/LPC sheared columns wide
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
     fresh(Nr);
     u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0), hb2 = make_uint4(0, 0, 0, 0);
     u32 Snext[NR];
-    const bool five = !UP && a.five;   // this down sweep also adds the (-1,0) volume and finishes the sum
+    constexpr bool five = !UP && FIVE;   // this down sweep also adds the (-1,0) volume and finishes the sum
     const u8* Hp2 = a.Hvol[1] + (size_t)pair * a.strideH;
     uint4 sb = make_uint4(0, 0, 0, 0);
     // S4B: the four-path partial sum fits a byte per disparity and travels as one byte per slot
@@ -965,8 +965,8 @@ int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int 
     if (a.five) {
         // -> and <- from the horizontal scan, the three downward paths and the winner-take-all in ONE sweep
         sgm2_hscan_kernel<true, true, LPC><<<gh, 256, 0, s>>>(a);
-        if (naturalOut) sgm2_shear_kernel<false, true, false, false, LPC><<<gs, 320, 0, s>>>(sa);
-        else sgm2_shear_kernel<false, true, true, false, LPC><<<gs, 320, 0, s>>>(sa);
+        if (naturalOut) sgm2_shear_kernel<false, true, false, false, LPC, true><<<gs, 320, 0, s>>>(sa);
+        else sgm2_shear_kernel<false, true, true, false, LPC, true><<<gs, 320, 0, s>>>(sa);
     } else if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
     else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
 #undef SGM2_SHEAR
