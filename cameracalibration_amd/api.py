@@ -226,6 +226,26 @@ def sgbm_compute(srcLeft, srcRight, params, ctx=None):
     return out
 
 
+def sgbm_compute_batch(lefts, rights, params, chunk=0, ctx=None):
+    """mdisp_sgbm over a sequence of host pairs (arrays N x H x W or lists of H x W uint8), with the copies
+    overlapped with the computation -> int16 N x H x W."""
+    Ls = [np.ascontiguousarray(a, dtype=np.uint8) for a in lefts]
+    Rs = [np.ascontiguousarray(a, dtype=np.uint8) for a in rights]
+    n = len(Ls)
+    if n != len(Rs):
+        raise ValueError("left / right count mismatch")
+    if n == 0:
+        return np.empty((0, 0, 0), np.int16)
+    H, W = Ls[0].shape
+    out = np.empty((n, H, W), dtype=np.int16)
+    ptrs = C.c_void_p * n
+    pl = ptrs(*[a.ctypes.data for a in Ls])
+    pr = ptrs(*[a.ctypes.data for a in Rs])
+    po = ptrs(*[out[i].ctypes.data for i in range(n)])
+    check(load().mdisp_sgbm_batch(_ctx(ctx), pl, pr, n, H, W, W, C.byref(params), po, chunk))
+    return out
+
+
 def sgbm_volume(srcLeft, srcRight, params, ctx=None):
     """Aggregated SGM cost volume S (uint16, H x W x numDisparities, biased by +P2 per path)."""
     L, R = _u8(srcLeft), _u8(srcRight)

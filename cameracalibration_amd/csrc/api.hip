@@ -650,6 +650,79 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     return md_check_sgm_error(c);
 }
 
+// A sequence of pairs in host memory, processed in chunks: the copies of chunk k+1 and of the results of
+// chunk k-1 travel on a second stream while chunk k is being computed.
+extern "C" int mdisp_sgbm_batch(mdisp_ctx* c, const uint8_t* const* lefts, const uint8_t* const* rights, int npairs, int rows, int cols,
+                                size_t step_bytes, const mdisp_sgbm_params* p, int16_t* const* disps, int chunk)
+{
+    MD_REQUIRE(c && lefts && rights && disps && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(npairs >= 0 && rows > 0 && cols > 0 && step_bytes >= (size_t)cols, MDISP_E_BADARG, "bad geometry");
+    if (npairs == 0) return MDISP_OK;
+    for (int i = 0; i < npairs; i++) MD_REQUIRE(lefts[i] && rights[i] && disps[i], MDISP_E_BADARG, "pair %d: null image", i);
+    if (chunk <= 0) chunk = 16;
+    if (chunk > npairs) chunk = npairs;
+    md_sgm_plan pl, plTail;
+    MD_TRY(md_sgm_plan_make(rows, cols, p, chunk, &pl));
+    const int nchunks = (npairs + chunk - 1) / chunk, tail = npairs - (nchunks - 1) * chunk;
+    MD_TRY(md_sgm_plan_make(rows, cols, p, tail, &plTail));
+    MD_HIP(hipSetDevice(c->device));
+    const int H = rows, W = cols;
+    const size_t pitch = md_align((size_t)W, 4), img = pitch * H, out = (size_t)H * W * 2;
+    Carver cv;
+    const size_t o_ws = cv.take(pl.total > plTail.total ? pl.total : plTail.total);
+    size_t o_in[2], o_out[2];
+    for (int s = 0; s < 2; s++) { o_in[s] = cv.take(2 * img * chunk); o_out[s] = cv.take(out * chunk); }
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev[6] = {};      // per slot: inputs uploaded, chunk computed, results downloaded
+    int rc = MDISP_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        mdisp_set_error("mdisp_sgbm_batch: %s -> %s", what, hipGetErrorString(e));
+        rc = MDISP_E_HIP;
+        return false;
+    };
+    if (!hip_ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate")) return rc;
+    for (int i = 0; i < 6 && rc == MDISP_OK; i++) hip_ok(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "hipEventCreate");
+    // the copy stream starts after whatever the context's stream still has in flight on this workspace
+    if (rc == MDISP_OK && hip_ok(hipEventRecord(ev[0], c->stream), "hipEventRecord")) hip_ok(hipStreamWaitEvent(copy, ev[0], 0), "hipStreamWaitEvent");
+    auto download = [&](int k) {          // results of chunk k
+        const int slot = k & 1, first = k * chunk, n = k == nchunks - 1 ? tail : chunk;
+        if (!hip_ok(hipStreamWaitEvent(copy, ev[2 + slot], 0), "hipStreamWaitEvent")) return;
+        for (int i = 0; i < n && rc == MDISP_OK; i++)
+            hip_ok(hipMemcpyAsync(disps[first + i], base + o_out[slot] + (size_t)i * out, out, hipMemcpyDeviceToHost, copy), "download");
+        if (rc == MDISP_OK) hip_ok(hipEventRecord(ev[4 + slot], copy), "hipEventRecord");
+    };
+    for (int k = 0; k < nchunks && rc == MDISP_OK; k++) {
+        const int slot = k & 1, first = k * chunk, n = k == nchunks - 1 ? tail : chunk;
+        if (k >= 2 && !hip_ok(hipStreamWaitEvent(copy, ev[2 + slot], 0), "hipStreamWaitEvent")) break;   // chunk k-2 has read this slot
+        u8* dIn = base + o_in[slot];
+        for (int i = 0; i < n && rc == MDISP_OK; i++) {
+            for (int side = 0; side < 2 && rc == MDISP_OK; side++) {
+                const uint8_t* src = side ? rights[first + i] : lefts[first + i];
+                u8* dst = dIn + ((size_t)side * chunk + i) * img;
+                if (step_bytes == pitch) hip_ok(hipMemcpyAsync(dst, src, img - (pitch - W), hipMemcpyHostToDevice, copy), "upload");
+                else hip_ok(hipMemcpy2DAsync(dst, pitch, src, step_bytes, W, H, hipMemcpyHostToDevice, copy), "upload");
+            }
+        }
+        if (rc != MDISP_OK || !hip_ok(hipEventRecord(ev[slot], copy), "hipEventRecord")) break;
+        if (!hip_ok(hipStreamWaitEvent(c->stream, ev[slot], 0), "hipStreamWaitEvent")) break;
+        if (k >= 2 && !hip_ok(hipStreamWaitEvent(c->stream, ev[4 + slot], 0), "hipStreamWaitEvent")) break;   // results of chunk k-2 are out
+        rc = md_sgm_run(c, k == nchunks - 1 ? plTail : pl, dIn, dIn + (size_t)chunk * img, pitch, img, (int16_t*)(base + o_out[slot]), base + o_ws);
+        if (rc != MDISP_OK || !hip_ok(hipEventRecord(ev[2 + slot], c->stream), "hipEventRecord")) break;
+        if (k >= 1) download(k - 1);
+    }
+    if (rc == MDISP_OK) download(nchunks - 1);
+    // drain both streams whatever happened, then release the per-call objects
+    (void)hipStreamSynchronize(copy);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 6; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+    (void)hipStreamDestroy(copy);
+    if (rc != MDISP_OK) return rc;
+    return md_check_sgm_error(c);
+}
+
 // Upload an 8-bit 1- or 3-channel image as it is (interleaved), rows at `dpitch`
 static int upload_u8(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch)
 {

@@ -187,6 +187,14 @@ int mdisp_asw_gifs(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const
  * L/R CV_8UC1; out CV_16S HxW, fixed point x16, invalid = (minDisparity-1)*16. */
 int mdisp_sgbm(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_sgbm_params* p, mdisp_image* out);
 
+/* mdisp_sgbm over a sequence of pairs held in host memory (the batch configuration): CV_8UC1 images of
+ * rows x cols with row stride step_bytes, disps[i] = rows*cols int16, contiguous.  Pairs are processed
+ * `chunk` at a time (<= 0 selects 16); uploads of the next chunk and downloads of the previous one run on
+ * a second stream while a chunk is computed.  Results equal npairs calls of mdisp_sgbm.  The reference
+ * processes one pair per call (methods/methods.cpp:1883-1921) and has no batch counterpart. */
+int mdisp_sgbm_batch(mdisp_ctx*, const uint8_t* const* lefts, const uint8_t* const* rights, int npairs, int rows, int cols,
+                     size_t step_bytes, const mdisp_sgbm_params* p, int16_t* const* disps, int chunk);
+
 /* The aggregated SGM cost volume S(y,x,d) = sum over paths of L_r, biased by +P2 per path (see the
  * recursion: L'(p,d) = C + min(L'(p-r,d), L'(p-r,d+-1)+P1, min L'(p-r)+P2) - min L'(p-r)), as uint16 [rows][cols][numDisparities] in host
  * memory.  No counterpart call in the reference (StereoSGBM keeps S private); exported so that

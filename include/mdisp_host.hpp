@@ -236,6 +236,35 @@ template <class M> void sgbmCompute(M left, M right, const mdisp_sgbm_params& p,
     detail::check(mdisp_sgbm(Context::forThisThread().handle(), &l, &r, &p, &d));
 }
 
+// the same over a sequence of pairs, copies overlapped with the computation (mdisp_sgbm_batch)
+template <class M> void sgbmComputeBatch(const std::vector<M>& lefts, const std::vector<M>& rights, const mdisp_sgbm_params& p,
+                                         std::vector<M>& disps16, int chunk = 0)
+{
+    typedef mat_traits<M> T;
+    const size_t n = lefts.size();
+    disps16.resize(n);
+    if (n == 0 || rights.size() != n) return;
+    std::vector<const uint8_t*> pl(n), pr(n);
+    std::vector<int16_t*> po(n);
+    const mdisp_image first = T::view(lefts[0]);
+    for (size_t i = 0; i < n; i++) {
+        const mdisp_image l = T::view(lefts[i]), r = T::view(rights[i]);
+        if (l.rows != first.rows || l.cols != first.cols || r.rows != first.rows || r.cols != first.cols || l.channels != 1 ||
+            r.channels != 1 || l.depth != MDISP_8U || r.depth != MDISP_8U || l.step_bytes != first.step_bytes ||
+            r.step_bytes != first.step_bytes) {
+            std::cout << "bad function parameters, please check image and window size." << std::endl;
+            disps16.clear();
+            return;
+        }
+        T::create(disps16[i], first.rows, first.cols, MDISP_16S, 1);
+        const mdisp_image d = T::view(disps16[i]);
+        if (d.step_bytes != (size_t)first.cols * 2) { disps16.clear(); return; }
+        pl[i] = static_cast<const uint8_t*>(l.data); pr[i] = static_cast<const uint8_t*>(r.data); po[i] = static_cast<int16_t*>(d.data);
+    }
+    detail::check(mdisp_sgbm_batch(Context::forThisThread().handle(), pl.data(), pr.data(), (int)n, first.rows, first.cols,
+                                   first.step_bytes, &p, po.data(), chunk));
+}
+
 // cv::StereoSGBM as the reference uses it (methods/methods.cpp:1216-1219, 1291, 1893, 1912): create() with the
 // library's argument order and defaults, compute() -> CV_16S x16.  Birchfield-Tomasi block cost, MODE_SGBM / MODE_HH.
 template <class M> class StereoSGBMT {

@@ -300,3 +300,21 @@ def test_reprojection_to_3d(api, orc):
         exp = orc.reproject_triangulate(disp, K, 152.63, colour)
         assert np.array_equal(got, exp)
     assert not got[3, 4].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,chunk,W", [(7, 3, 72), (5, 0, 70), (1, 4, 72), (12, 6, 64)])
+def test_sgm_host_batch_streams_chunks(api, orc, n, chunk, W):
+    # pairs in host memory, processed chunk by chunk with the copies on a second stream; ragged last chunk,
+    # a width that is not a multiple of 4 (pitched copies), a chunk larger than the sequence
+    H, D = 36, 48
+    p = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+    Ls, Rs = [], []
+    for i in range(n):
+        L, R, _ = api.synth_pair(0x5EED0101 + 2 * i, H, W, D)
+        Ls.append(L)
+        Rs.append(R)
+    got = api.sgbm_compute_batch(Ls, Rs, p, chunk)
+    assert got.shape == (n, H, W)
+    for i in range(n):
+        assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], 0, D, 8, 32, 10, 1, 8, 1))
