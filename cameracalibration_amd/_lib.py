@@ -48,7 +48,7 @@ EXPORTS = [
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
-    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch",
+    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load():
     lib.mdisp_stereosgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, ssp]
     lib.mdisp_stereosgbm_workspace_bytes.restype = C.c_size_t
     lib.mdisp_stereosgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, ssp, vp, vp, C.c_size_t]
+    lib.mdisp_legacy_disparity.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, img]
     lib.mdisp_sgbm_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, sgp, vp, C.c_int]
     lib.mdisp_sgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_sgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, sgp]

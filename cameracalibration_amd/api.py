@@ -412,3 +412,71 @@ def synth_pair(seed, rows, cols, numDisp):
     gt = np.empty((rows, cols), dtype=np.uint16)
     check(load().mdisp_synth_pair(seed, rows, cols, numDisp, left.ctypes.data, right.ctypes.data, gt.ctypes.data))
     return left, right, gt
+
+
+# ---- namespace stereomatch_1 (methods/method_StereoMatching.h:94-112): fixed-window matchers ----
+(LEGACY_AD, LEGACY_SAD, LEGACY_SAD_INTE, LEGACY_SAD_BF, LEGACY_TAD, LEGACY_STAD, LEGACY_STAD_INTE, LEGACY_STAD_BF,
+ LEGACY_SD, LEGACY_SSD, LEGACY_SSD_INTE, LEGACY_SSD_BF) = range(12)
+
+
+def _legacy(method, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity, ctx):
+    L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+    if method not in (LEGACY_AD, LEGACY_TAD, LEGACY_SD) and winSize % 2 == 0:
+        print("winsize must be odd")               # method_StereoMatching.cpp:99-103
+        return None
+    out = np.empty(L.shape[:2], dtype=np.uint8)
+    check(load().mdisp_legacy_disparity(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), method, winSize, threshold_T, minDisparity,
+                                        numDisparity, C.byref(image(out))))
+    return out
+
+
+class stereomatch_1:
+    """The reference's namespace of the same name: same function names, argument order and defaults."""
+
+    @staticmethod
+    def computeAD(leftImg, rightImg, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_AD, leftImg, rightImg, 1, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSAD(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SAD, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSAD_inteOpti(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SAD_INTE, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSAD_BFOpti(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SAD_BF, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeTAD(leftImg, rightImg, threshold_T=30, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_TAD, leftImg, rightImg, 1, threshold_T, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSTAD(leftImg, rightImg, winSize=7, threshold_T=30, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_STAD, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSTAD_inteOpti(leftImg, rightImg, winSize=7, threshold_T=30, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_STAD_INTE, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSTAD_BFOpti(leftImg, rightImg, winSize=7, threshold_T=30, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_STAD_BF, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSD(leftImg, rightImg, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SD, leftImg, rightImg, 1, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSSD(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SSD, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSSD_inteOpti(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SSD_INTE, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeSSD_BFOpti(leftImg, rightImg, winSize=7, minDisparity=0, numDisparity=30, ctx=None):
+        return _legacy(LEGACY_SSD_BF, leftImg, rightImg, winSize, 0, minDisparity, numDisparity, ctx)

@@ -650,6 +650,30 @@ extern "C" int mdisp_sgbm(mdisp_ctx* c, const mdisp_image* L, const mdisp_image*
     return md_check_sgm_error(c);
 }
 
+extern "C" int mdisp_legacy_disparity(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, int method, int winSize, int T,
+                                      int minD, int numD, mdisp_image* out)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_8U, 1, "out"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols;
+    const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
+    Carver cv;
+    size_t o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_st = cv.take(p3 * H), o_d = cv.take(pitch * H);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
+    if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
+    if ((rc = md_legacy_disparity(c->stream, base + o_l, pitch, base + o_r, pitch, H, W, method, winSize, T, minD, numD, base + o_d, pitch)))
+        return rc;
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, pitch, W, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 // A sequence of pairs in host memory, processed in chunks: the copies of chunk k+1 and of the results of
 // chunk k-1 travel on a second stream while chunk k is being computed.
 extern "C" int mdisp_sgbm_batch(mdisp_ctx* c, const uint8_t* const* lefts, const uint8_t* const* rights, int npairs, int rows, int cols,

@@ -115,6 +115,10 @@ int md_median3_s16(hipStream_t s, const int16_t* src, int H, int W, int16_t* dst
 size_t md_speckle_scratch_bytes(int H, int W);
 int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal, int maxSize, int maxDiff, void* scratch);
 
+// legacy.hip: fixed-window matchers of namespace stereomatch_1
+int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, size_t rp, int H, int W, int method, int winSize,
+                        int T, int minD, int numD, u8* dOut, size_t op);
+
 // stereo.hip
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                     int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op);

@@ -118,6 +118,14 @@ typedef struct mdisp_sgbm_params {
     int censusMethod;       /* MDISP_BASIC_CENSUS / ROTATION_INVARIANT / UNIFORM                  */
 } mdisp_sgbm_params;
 
+/* The fixed-window matchers of namespace stereomatch_1, methods/method_StereoMatching.h:94-112
+ * (method_StereoMatching.cpp:32-869). */
+enum {
+    MDISP_LEGACY_AD = 0, MDISP_LEGACY_SAD = 1, MDISP_LEGACY_SAD_INTE = 2, MDISP_LEGACY_SAD_BF = 3,
+    MDISP_LEGACY_TAD = 4, MDISP_LEGACY_STAD = 5, MDISP_LEGACY_STAD_INTE = 6, MDISP_LEGACY_STAD_BF = 7,
+    MDISP_LEGACY_SD = 8, MDISP_LEGACY_SSD = 9, MDISP_LEGACY_SSD_INTE = 10, MDISP_LEGACY_SSD_BF = 11
+};
+
 /* Arguments of cv::StereoSGBM::create, in its order (methods/methods.cpp:1893: create(0, 48, 7);
  * :1216-1219, :1565-1568: create(0,64,7,490,1960,1,63,10,100,32,MODE_SGBM)), for the entry points
  * that run StereoSGBM with its own Birchfield-Tomasi block cost. */
@@ -218,6 +226,14 @@ int mdisp_stereosgbm_stages(mdisp_ctx*, const mdisp_image* left, const mdisp_ima
 int mdisp_median_blur3_s16(mdisp_ctx*, const mdisp_image* src, mdisp_image* dst);
 /* cv::filterSpeckles(img, newVal, maxSpeckleSize, maxDiff) on CV_16SC1, in place. */
 int mdisp_filter_speckles_s16(mdisp_ctx*, mdisp_image* img, int newVal, int maxSpeckleSize, int maxDiff);
+
+/* stereomatch_1::computeAD / SAD / SAD_inteOpti / SAD_BFOpti / TAD / STAD* / SD / SSD*
+ * (methods/method_StereoMatching.cpp:32-869).  left/right CV_8UC1 or BGR (converted to gray as the reference
+ * does); numDisparity is a COUNT; out CV_8U = (char)(16 * winning index), 0 outside the evaluated region.
+ * winSize is ignored by AD / TAD / SD, threshold_T by everything but the T variants (where it clamps the
+ * winning index, as the reference does).  An even winSize fails with MDISP_E_BADARG ("winsize must be odd"). */
+int mdisp_legacy_disparity(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, int method, int winSize,
+                           int threshold_T, int minDisparity, int numDisparity, mdisp_image* out);
 
 /* LR consistency check of PatchMatch::postProcess, methods/patchmatch.cpp:817-828.
  * dL/dR CV_32F, validL/validR CV_8U (1 = consistent within `thresh`). */

@@ -126,3 +126,19 @@ inline void getRectifiedImages(cv::Mat imgLeft, cv::Mat imgRight, std::string ca
 }
 
 #endif  // MDISP_CV_HPP
+
+// methods/method_StereoMatching.h:94-112 (namespace stereomatch_1): the fixed-window matchers on cv::Mat
+namespace stereomatch_1 {
+inline cv::Mat computeAD(cv::Mat l, cv::Mat r, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeAD(l, r, minDisparity, numDisparity); }
+inline cv::Mat computeSAD(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSAD(l, r, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeSAD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSAD_inteOpti(l, r, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeSAD_BFOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSAD_BFOpti(l, r, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeTAD(cv::Mat l, cv::Mat r, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeTAD(l, r, threshold_T, minDisparity, numDisparity); }
+inline cv::Mat computeSTAD(cv::Mat l, cv::Mat r, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSTAD(l, r, winSize, threshold_T, minDisparity, numDisparity); }
+inline cv::Mat computeSTAD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSTAD_inteOpti(l, r, winSize, threshold_T, minDisparity, numDisparity); }
+inline cv::Mat computeSTAD_BFOpti(cv::Mat l, cv::Mat r, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSTAD_BFOpti(l, r, winSize, threshold_T, minDisparity, numDisparity); }
+inline cv::Mat computeSD(cv::Mat l, cv::Mat r, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSD(l, r, minDisparity, numDisparity); }
+inline cv::Mat computeSSD(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD(l, r, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeSSD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_inteOpti(l, r, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeSSD_BFOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_BFOpti(l, r, winSize, minDisparity, numDisparity); }
+}  // namespace stereomatch_1

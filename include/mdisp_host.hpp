@@ -356,5 +356,47 @@ template <class M> void reprojectTriangulate(M disparityMap, const double K_new[
 typedef StereoMatchParamT<Mat> StereoMatchParam;
 typedef StereoSGBMT<Mat> StereoSGBM;
 
+// namespace stereomatch_1, methods/method_StereoMatching.h:94-112: the fixed-window matchers with the
+// reference's names, argument order, defaults and error behaviour ("winsize must be odd" + empty image).
+namespace stereomatch_1 {
+template <class M> M legacy_(int method, M leftImg, M rightImg, int winSize, int threshold_T, int minDisparity, int numDisparity)
+{
+    typedef mat_traits<M> T;
+    const bool windowed = method != MDISP_LEGACY_AD && method != MDISP_LEGACY_TAD && method != MDISP_LEGACY_SD;
+    if (windowed && winSize % 2 == 0) { std::cout << "winsize must be odd" << std::endl; return M(); }
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    M out;
+    T::create(out, l.rows, l.cols, MDISP_8U, 1);
+    mdisp_image o = T::view(out);
+    detail::check(mdisp_legacy_disparity(Context::forThisThread().handle(), &l, &r, method, winSize, threshold_T, minDisparity,
+                                         numDisparity, &o));
+    return out;
+}
+template <class M> M computeAD(M leftImg, M rightImg, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_AD, leftImg, rightImg, 1, 0, minDisparity, numDisparity); }
+template <class M> M computeSAD(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SAD, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+template <class M> M computeSAD_inteOpti(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SAD_INTE, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+template <class M> M computeSAD_BFOpti(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SAD_BF, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+template <class M> M computeTAD(M leftImg, M rightImg, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_TAD, leftImg, rightImg, 1, threshold_T, minDisparity, numDisparity); }
+template <class M> M computeSTAD(M leftImg, M rightImg, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_STAD, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity); }
+template <class M> M computeSTAD_inteOpti(M leftImg, M rightImg, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_STAD_INTE, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity); }
+template <class M> M computeSTAD_BFOpti(M leftImg, M rightImg, int winSize = 7, int threshold_T = 30, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_STAD_BF, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity); }
+template <class M> M computeSD(M leftImg, M rightImg, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SD, leftImg, rightImg, 1, 0, minDisparity, numDisparity); }
+template <class M> M computeSSD(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SSD, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+template <class M> M computeSSD_inteOpti(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SSD_INTE, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+template <class M> M computeSSD_BFOpti(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return legacy_<M>(MDISP_LEGACY_SSD_BF, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+}  // namespace stereomatch_1
+
 }  // namespace mdisp
 #endif  // MDISP_HOST_HPP

@@ -61,6 +61,15 @@ typedef struct {
     int censusMethod;
 } orc_sgm_params;
 
+/* fixed-window matchers of namespace stereomatch_1 (methods/method_StereoMatching.cpp:32-869) */
+enum {
+    ORC_LEGACY_AD = 0, ORC_LEGACY_SAD = 1, ORC_LEGACY_SAD_INTE = 2, ORC_LEGACY_SAD_BF = 3,
+    ORC_LEGACY_TAD = 4, ORC_LEGACY_STAD = 5, ORC_LEGACY_STAD_INTE = 6, ORC_LEGACY_STAD_BF = 7,
+    ORC_LEGACY_SD = 8, ORC_LEGACY_SSD = 9, ORC_LEGACY_SSD_INTE = 10, ORC_LEGACY_SSD_BF = 11
+};
+int orc_legacy_disparity(const uint8_t* L, const uint8_t* R, int H, int W, int method, int winSize, int T, int minD, int numD,
+                         uint8_t* out);
+
 /* cv::StereoSGBM parameters (create() argument order) */
 enum { ORC_SGBM_MODE_SGBM = 0, ORC_SGBM_MODE_HH = 1 };
 typedef struct {

@@ -352,3 +352,17 @@ def filter_speckles_s16(img, newVal, maxSpeckleSize, maxDiff):
     out = np.ascontiguousarray(img, np.int16).copy()
     lib().orc_filter_speckles_s16(_p(out), out.shape[0], out.shape[1], newVal, maxSpeckleSize, maxDiff)
     return out
+
+
+(LEGACY_AD, LEGACY_SAD, LEGACY_SAD_INTE, LEGACY_SAD_BF, LEGACY_TAD, LEGACY_STAD, LEGACY_STAD_INTE, LEGACY_STAD_BF,
+ LEGACY_SD, LEGACY_SSD, LEGACY_SSD_INTE, LEGACY_SSD_BF) = range(12)
+
+
+def legacy_disparity(L, R, method, winSize=7, threshold_T=30, minDisparity=0, numDisparity=30):
+    """stereomatch_1::computeAD ... computeSSD_BFOpti (methods/method_StereoMatching.cpp:32-869) -> uint8, or None
+    where the reference would refuse or throw."""
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    out = np.empty((H, W), np.uint8)
+    rc = lib().orc_legacy_disparity(_p(L), _p(R), H, W, method, winSize, threshold_T, minDisparity, numDisparity, _p(out))
+    return None if rc else out

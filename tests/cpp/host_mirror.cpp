@@ -23,6 +23,10 @@ int main(int argc, char** argv)
         d = censusStereo(p, BASIC_CENSUS);
         if (!d.empty()) return fail("censusStereo on empty input must give an empty image");
     }
+    {   // stereomatch_1: even window -> "winsize must be odd" + empty image (method_StereoMatching.cpp:99-103)
+        Mat a(8, 8, MDISP_8U), b(8, 8, MDISP_8U);
+        if (!stereomatch_1::computeSAD(a, b, 6).empty()) return fail("even winSize must give an empty image (stereomatch_1)");
+    }
     if (argc < 6 || std::strcmp(argv[1], "gpu") != 0) { std::printf("OK (no-GPU checks)\n"); return 0; }
 
     const int H = std::atoi(argv[2]), W = std::atoi(argv[3]), maxD = std::atoi(argv[4]);
@@ -59,6 +63,9 @@ int main(int argc, char** argv)
     if (dBt.empty() || dG.empty()) return fail("empty StereoSGBM output");
     std::fwrite(dBt.data(), 2, (size_t)H * W, f);
     std::fwrite(dG.data(), 2, (size_t)H * W, f);
+    Mat dLeg = stereomatch_1::computeSSD_BFOpti(L, R, 7, 0, maxD + 1);                                        // method_StereoMatching.h:112
+    if (dLeg.empty()) return fail("empty stereomatch_1 output");
+    std::fwrite(dLeg.data(), 1, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

@@ -22,6 +22,7 @@ def test_host_layer_error_behaviour_matches_reference():
     r = subprocess.run([_exe()], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad function parameters, please check image and window size." in r.stdout
+    assert "winsize must be odd" in r.stdout
     assert "OK (no-GPU checks)" in r.stdout
 
 
@@ -52,7 +53,9 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     cen = buf[o:o + n].reshape(H, W); o += n
     dO = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
     dBt = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
-    dG = buf[o:o + 2 * n].view(np.int16).reshape(H, W)
+    dG = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
+    dLeg = buf[o:o + n].reshape(H, W)
+    assert np.array_equal(dLeg, orc.legacy_disparity(L, R, orc.LEGACY_SSD_BF, 7, 30, 0, maxD + 1))
     assert np.array_equal(dBt, orc.sgbm_bt(L, R, 0, 32, 7, 490, 1960, 1, 63, 10, 100, 32, orc.MODE_SGBM))
     assert np.array_equal(dG, np.rint(orc.sgbm_bt(L, R, 0, 48, 7).astype(np.float64) / 16.0).astype(np.int16))
     assert np.array_equal(dC, orc.census_stereo(L, R, 7, 0, maxD, True, orc.BASIC_CENSUS, orc.AGG_BOX))

@@ -325,3 +325,24 @@ def test_median_and_speckle_restatements(orc):
     assert (out[2:4, 2:4] == -16).all() and out[0, 0] == 160 and out[6, 6] == -16
     assert np.array_equal(orc.filter_speckles_s16(img, -16, 3, 16), img)
     assert (orc.filter_speckles_s16(img, -16, 4, 1000) == img).all()    # one big region when everything connects
+
+
+def test_legacy_matchers_known_answers(orc):
+    # a pure shift by 5 columns: every window matcher's first zero-cost candidate is index 5 -> (char)(16 * 5) inside
+    # the evaluated region; the frame the reference never writes stays 0
+    rng = np.random.default_rng(11)
+    R = rng.integers(0, 256, (30, 90)).astype(np.uint8)
+    L = np.roll(R, 5, axis=1)
+    for m in (orc.LEGACY_SAD, orc.LEGACY_SAD_INTE, orc.LEGACY_SSD, orc.LEGACY_SSD_INTE, orc.LEGACY_SSD_BF, orc.LEGACY_STAD_BF):
+        d = orc.legacy_disparity(L, R, m, 7, 30, 0, 16)
+        assert (d[3:-3, 24:-3] == 80).all(), m
+        assert (d[:3] == 0).all() and (d[:, :3] == 0).all()
+    assert (orc.legacy_disparity(L, R, orc.LEGACY_SAD_BF, 7, 30, 0, 16)[4:-4, 24:-4] == 80).all()
+    # the T variants clamp the winning index, not the cost
+    assert (orc.legacy_disparity(L, R, orc.LEGACY_STAD, 7, 3, 0, 16)[3:-3, 24:-3] == 48).all()
+    # AD reads the left pixel through at<char>: values above 127 count as 0, and candidate k is column i - numDisparity + k
+    Lc = np.full((4, 40), 200, np.uint8)
+    Rc = np.tile(np.arange(40, dtype=np.uint8), (4, 1))
+    d = orc.legacy_disparity(Lc, Rc, orc.LEGACY_AD, 1, 0, 0, 8)
+    assert (d[:, 8:] == 0).all()               # |0 - R| is smallest at the first candidate (smallest column)
+    assert orc.legacy_disparity(L, R, orc.LEGACY_SAD, 6, 30, 0, 16) is None      # even window
