@@ -271,7 +271,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
 // the 19 x NR table of masks fused_wta() uses: row t covers best - (lane base) = t - 1
 __device__ __forceinline__ void init_excl_mask(u32 (*exclMask)[NR])
 {
-    for (int i = threadIdx.x; i < 19 * NR; i += 256) {
+    for (int i = threadIdx.x; i < 19 * NR; i += blockDim.x) {
         const int t = i / NR, r = i % NR, rel = t - 1;
         const int elo = 4 * (r >> 1) + (r & 1), ehi = elo + 2;
         u32 m = 0;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
 // Diagonal pre-pass: run a path along its whole line and keep the state wherever it leaves a strip.
 // One lane-row per line, 16 lines per workgroup; W+H-1 lines per direction, directions in the
 // order (1,1) (-1,1) (1,-1) (-1,-1).
-template <bool TAIL>
+template <bool TAIL, int CW = 16>
 __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 {
     const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 // ---------------------------------------------------------------------------------------------
 // Main sweep.  UP = false: (0,1) (1,1) (-1,1) top to bottom, S <- H(1,0) + the three.
 //              UP = true : (0,-1) (1,-1) (-1,-1) bottom to top, S8 = S + H(-1,0) + the three.
-template <bool UP, bool TAIL, bool U8, bool FUSE>
+// PFD rows of operands are in flight per lane-row: 1 when many waves share a SIMD, more when a small batch
+// leaves one wave per SIMD and a row is shorter than a memory round trip.
+template <bool UP, bool TAIL, bool U8, bool FUSE, int CW = 16, int PFD = 1>
 __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
 {
     // diagonal path states of the previous / current row: [row parity][x-1 / x+1 family][column][...],
@@ -419,40 +421,43 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     // which strip-border state this lane-row consumes (none for interior columns)
     const bool edgeA = lr == 0 && x != 0;              // predecessor x-1 belongs to the strip on the left
     const bool edgeB = lr == cw - 1 && x != W - 1;     // predecessor x+1 belongs to the strip on the right
-    // operands of the next row are requested before the current row is computed
-    u32 cl = 0; uint4 rb = make_uint4(0, 0, 0, 0), hb = make_uint4(0, 0, 0, 0); u32 Snext[NR], Hnext[NR], BnA[NR], BnB[NR];
-    auto fetch_row = [&](int r) {
+    // operands of later rows are requested before the current row is computed
+    struct RowIn { u32 cl; uint4 rb, hb; u32 Snext[NR], Hnext[NR], BnA[NR], BnB[NR]; };
+    RowIn ring[PFD];
+    auto fetch_row = [&](int r, RowIn& in) {
         const int y = ys + sy * r;
-        load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
+        load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, in.cl, in.rb);
         const size_t pix = (size_t)y * W + x;
-        if (U8) hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
-        else load8(reinterpret_cast<const u16*>(Hp + pix * 512) + lic * DPL, Hnext);
-        if (readS) load8(Sp + (pix * 256 + lic * DPL), Snext);
+        if (U8) in.hb = *reinterpret_cast<const uint4*>(Hp + pix * 256 + lic * 16);
+        else load8(reinterpret_cast<const u16*>(Hp + pix * 512) + lic * DPL, in.Hnext);
+        if (readS) load8(Sp + (pix * 256 + lic * DPL), in.Snext);
         if (r > 0) {
-            if (edgeA) load8(bA + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnA);
-            if (edgeB) load8(bB + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), BnB);
+            if (edgeA) load8(bA + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), in.BnA);
+            if (edgeB) load8(bB + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), in.BnB);
         }
     };
-    if (colActive) fetch_row(0);
-    for (int r = 0; r < H; r++) {
+#pragma unroll
+    for (int u = 0; u < PFD; u++)
+        if (colActive && u < H) fetch_row(u, ring[u]);
+    auto process_row = [&](int r, RowIn& in) {
         const int y = ys + sy * r;
         const bool hasPrevRow = r > 0;
         const int par = r & 1;
         if (colActive) {
             u16* sp = Sp + (((size_t)y * W + x) * 256 + lic * DPL);
             u32 C[NR], L[NR], Sacc[NR], NA[NR], NB[NR];
-            cost_from_operands(cl, rb, C);
-            if (U8) unpack_bytes(hb, Sacc);
+            cost_from_operands(in.cl, in.rb, C);
+            if (U8) unpack_bytes(in.hb, Sacc);
             else {
 #pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = Hnext[q];
+                for (int q = 0; q < NR; q++) Sacc[q] = in.Hnext[q];
             }
 #pragma unroll
             for (int q = 0; q < NR; q++) {
-                if (readS) Sacc[q] = pkadd(Sacc[q], Snext[q]);
-                NA[q] = BnA[q]; NB[q] = BnB[q];
+                if (readS) Sacc[q] = pkadd(Sacc[q], in.Snext[q]);
+                NA[q] = in.BnA[q]; NB[q] = in.BnB[q];
             }
-            if (r + 1 < H) fetch_row(r + 1);
+            if (r + PFD < H) fetch_row(r + PFD, in);
             // vertical
             sgm_step<TAIL>(Nv, C, P1P1, P2P2, tail, L);
 #pragma unroll
@@ -529,6 +534,14 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
             } else store8(sp, Sacc);
         }
         __syncthreads();   // diag[par] complete before the next row reads it
+    };
+    for (int r0 = 0; r0 < H; r0 += PFD) {
+#pragma unroll
+        for (int u = 0; u < PFD; u++) {
+            const int r = r0 + u;
+            if (r >= H) break;
+            process_row(r, ring[u]);
+        }
     }
 }
 
@@ -914,7 +927,7 @@ static size_t shear_hand_bytes(int H, int W, int lpc) { return md_align((size_t)
 static size_t shear_sync_bytes(int H, int W, int batch, int lpc)
 { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, 256 / lpc)) * sizeof(int), 256); }
 
-struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, slots, mode; bool u8m; };
+struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, slots, mode, cw; bool u8m; };
 static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
 {
     Sgm2Layout l;
@@ -922,7 +935,8 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
     l.mode = sgm2_mode(pl);
     l.lpc = lanes_per_pixel(pl);
     l.slots = l.lpc * DPL;
-    l.nstrips = (pl.W + CW - 1) / CW;
+    l.cw = CW;
+    l.nstrips = (pl.W + l.cw - 1) / l.cw;
     if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc); }   // hand-off rows
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
