@@ -49,6 +49,7 @@ EXPORTS = [
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
+    "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
 ]
 
 _lib = None
@@ -103,6 +104,13 @@ def load():
     lib.mdisp_stereosgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, ssp]
     lib.mdisp_stereosgbm_workspace_bytes.restype = C.c_size_t
     lib.mdisp_stereosgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, ssp, vp, vp, C.c_size_t]
+    dp = C.POINTER(C.c_double)
+    lib.mdisp_rectify_maps_create.argtypes = [vp, dp, dp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mdisp_rectify_maps_destroy.argtypes = [vp]
+    lib.mdisp_rectify_maps_destroy.restype = None
+    lib.mdisp_rectify_maps_download.argtypes = [vp, vp, vp, vp]
+    lib.mdisp_remap_with.argtypes = [vp, vp, img, img]
+    lib.mdisp_remap_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     lib.mdisp_legacy_disparity.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, img]
     lib.mdisp_sgbm_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, sgp, vp, C.c_int]
     lib.mdisp_sgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]

@@ -355,6 +355,55 @@ def initUndistortRectifyMap(K, dist, R, P, size):
     return m1, m2
 
 
+class RectifyMaps:
+    """Device-resident maps of cv::initUndistortRectifyMap(K, dist, R, P, size, CV_16SC2), built on the GPU once and
+    reused for every frame: `maps.remap(img)` = cv::remap(img, ..., INTER_LINEAR)."""
+
+    def __init__(self, K, dist, R, P, size, ctx=None):
+        W, H = size
+        self.size = (W, H)
+        self._ctx = ctx
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        if P.size == 9:
+            P = np.hstack([P.reshape(3, 3), np.zeros((3, 1))])
+        P = np.ascontiguousarray(P.reshape(12))
+        dist = np.ascontiguousarray(dist, dtype=np.float64).reshape(-1)
+        dp = C.POINTER(C.c_double)
+        self._h = C.c_void_p()
+        check(load().mdisp_rectify_maps_create(_ctx(ctx), K.ctypes.data_as(dp), dist.ctypes.data_as(dp), dist.size,
+                                               R.ctypes.data_as(dp), P.ctypes.data_as(dp), W, H, C.byref(self._h)))
+
+    def download(self):
+        W, H = self.size
+        m1 = np.empty((H, W, 2), dtype=np.int16)
+        m2 = np.empty((H, W), dtype=np.uint16)
+        check(load().mdisp_rectify_maps_download(_ctx(self._ctx), self._h, m1.ctypes.data, m2.ctypes.data))
+        return m1, m2
+
+    def remap(self, src):
+        src = _u8(src)
+        W, H = self.size
+        dst = np.empty((H, W) + ((src.shape[2],) if src.ndim == 3 else ()), dtype=np.uint8)
+        check(load().mdisp_remap_with(_ctx(self._ctx), self._h, C.byref(image(src)), C.byref(image(dst))))
+        return dst
+
+    def remap_dev(self, d_src, src_pitch, src_rows, src_cols, channels, d_dst, dst_pitch):
+        check(load().mdisp_remap_dev(_ctx(self._ctx), self._h, d_src, src_pitch, src_rows, src_cols, channels, d_dst, dst_pitch))
+
+    def close(self):
+        if self._h:
+            load().mdisp_rectify_maps_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def stereoRectify(K1, D1, K2, D2, size, R, T, zero_disparity=True, alpha=-1.0):
     """cv::stereoRectify as called at methods/methods.cpp:1691-1694 (newImageSize = imageSize).
     Returns (R1, R2, P1, P2, Q, roi1, roi2)."""

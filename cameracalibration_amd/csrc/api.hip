@@ -901,6 +901,89 @@ extern "C" int mdisp_lr_check(mdisp_ctx* c, const mdisp_image* dL, const mdisp_i
     return MDISP_OK;
 }
 
+// ---- device-resident rectification maps: built once per calibration on the GPU, reused for every frame ----
+struct mdisp_rectify_maps { int device, W, H; int16_t* m1; u16* m2; };
+
+extern "C" int mdisp_rectify_maps_create(mdisp_ctx* c, const double K[9], const double* dist, int ndist, const double R[9],
+                                         const double P[12], int width, int height, mdisp_rectify_maps** out)
+{
+    MD_REQUIRE(c && out && width > 0 && height > 0, MDISP_E_BADARG, "null argument or empty size");
+    *out = nullptr;
+    double ir[9], k[8];
+    MD_TRY(md_rectify_map_setup(K, dist, ndist, R, P, ir, k));
+    MD_HIP(hipSetDevice(c->device));
+    mdisp_rectify_maps* m = new (std::nothrow) mdisp_rectify_maps();
+    MD_REQUIRE(m, MDISP_E_NOMEM, "out of host memory");
+    m->device = c->device; m->W = width; m->H = height; m->m1 = nullptr; m->m2 = nullptr;
+    const size_t n = (size_t)width * height;
+    if (hipMalloc((void**)&m->m1, n * 4) != hipSuccess || hipMalloc((void**)&m->m2, n * 2) != hipSuccess) {
+        if (m->m1) (void)hipFree(m->m1);
+        delete m;
+        mdisp_set_error("hipMalloc of the rectification maps (%zu bytes) failed", n * 6);
+        return MDISP_E_NOMEM;
+    }
+    int rc = md_rectify_maps(c->stream, ir, k, K[0], K[4], K[2], K[5], width, height, m->m1, m->m2);
+    if (rc == MDISP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { mdisp_set_error("rectification map kernel failed"); rc = MDISP_E_HIP; }
+    if (rc != MDISP_OK) { (void)hipFree(m->m1); (void)hipFree(m->m2); delete m; return rc; }
+    *out = m;
+    return MDISP_OK;
+}
+
+extern "C" void mdisp_rectify_maps_destroy(mdisp_rectify_maps* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(m->m1); (void)hipFree(m->m2);
+    delete m;
+}
+
+extern "C" int mdisp_rectify_maps_download(mdisp_ctx* c, const mdisp_rectify_maps* m, int16_t* map1, uint16_t* map2)
+{
+    MD_REQUIRE(c && m && map1 && map2, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(m->device == c->device, MDISP_E_BADARG, "maps live on device %d, context on %d", m->device, c->device);
+    MD_HIP(hipSetDevice(c->device));
+    const size_t n = (size_t)m->W * m->H;
+    MD_HIP(hipMemcpyAsync(map1, m->m1, n * 4, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipMemcpyAsync(map2, m->m2, n * 2, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_remap_dev(mdisp_ctx* c, const mdisp_rectify_maps* m, const uint8_t* d_src, size_t src_pitch, int src_rows, int src_cols,
+                               int channels, uint8_t* d_dst, size_t dst_pitch)
+{
+    MD_REQUIRE(c && m && d_src && d_dst, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(m->device == c->device, MDISP_E_BADARG, "maps live on device %d, context on %d", m->device, c->device);
+    MD_REQUIRE(src_rows > 0 && src_cols > 0 && (channels == 1 || channels == 3) && src_pitch >= (size_t)src_cols * channels &&
+               dst_pitch >= (size_t)m->W * channels, MDISP_E_BADARG, "bad geometry");
+    MD_HIP(hipSetDevice(c->device));
+    return md_remap(c->stream, d_src, src_pitch, src_rows, src_cols, channels, m->m1, m->m2, m->H, m->W, d_dst, dst_pitch);
+}
+
+extern "C" int mdisp_remap_with(mdisp_ctx* c, const mdisp_rectify_maps* m, const mdisp_image* src, mdisp_image* dst)
+{
+    MD_REQUIRE(c && m, MDISP_E_BADARG, "null argument");
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    MD_REQUIRE(src->depth == MDISP_8U && dst->depth == MDISP_8U && src->channels == dst->channels &&
+               (src->channels == 1 || src->channels == 3), MDISP_E_BADARG, "remap needs CV_8UC1 or CV_8UC3 images");
+    MD_REQUIRE(dst->rows == m->H && dst->cols == m->W, MDISP_E_BADARG, "dst must have the size of the maps (%dx%d)", m->W, m->H);
+    MD_REQUIRE(m->device == c->device, MDISP_E_BADARG, "maps live on device %d, context on %d", m->device, c->device);
+    MD_HIP(hipSetDevice(c->device));
+    const int sH = src->rows, sW = src->cols, cn = src->channels;
+    const size_t sp = md_align((size_t)sW * cn, 256), dp = md_align((size_t)m->W * cn, 256);
+    Carver cv;
+    size_t o_s = cv.take(sp * sH), o_d = cv.take(dp * m->H);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base + o_s, sp, src->data, src->step_bytes, (size_t)sW * cn, sH));
+    if ((rc = md_remap(c->stream, base + o_s, sp, sH, sW, cn, m->m1, m->m2, m->H, m->W, base + o_d, dp))) return rc;
+    MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + o_d, dp, (size_t)m->W * cn, m->H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 extern "C" int mdisp_remap(mdisp_ctx* c, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst)
 {
     MD_REQUIRE(c && map1 && map2, MDISP_E_BADARG, "null argument");

@@ -130,6 +130,10 @@ int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, f
 int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
              int dH, int dW, u8* dst, size_t dp);
 
+int md_rectify_maps(hipStream_t s, const double ir[9], const double k[8], double fx, double fy, double u0, double v0, int W, int H,
+                    int16_t* m1, u16* m2);
+// host.hip: the inverse of P[:3,:3]*R and the padded distortion vector of initUndistortRectifyMap
+int md_rectify_map_setup(const double K[9], const double* dist, int ndist, const double R[9], const double P[12], double ir[9], double k[8]);
 int md_reproject_q(hipStream_t s, const float* disp, int H, int W, const double Q[16], float* xyz);
 int md_reproject_tri(hipStream_t s, const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz);
 

@@ -35,6 +35,19 @@ static inline int round_sat_i32(double v)
     return (int)lrint(v);   // round half to even, as cvRound
 }
 
+int md_rectify_map_setup(const double K[9], const double* dist, int ndist, const double R[9], const double P[12], double ir[9], double k[8])
+{
+    MD_REQUIRE(K && R && P, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(ndist == 0 || dist, MDISP_E_BADARG, "null distortion vector");
+    MD_REQUIRE(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8, MDISP_E_BADARG, "distortion vector must have 0, 4, 5 or 8 entries");
+    const double Ar[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    double ArR[9];
+    mul33(Ar, R, ArR);
+    MD_REQUIRE(inv33(ArR, ir), MDISP_E_BADARG, "P[:3,:3]*R is singular");
+    for (int i = 0; i < 8; i++) k[i] = i < ndist ? dist[i] : 0.0;
+    return MDISP_OK;
+}
+
 // cv::initUndistortRectifyMap(K, D, R, P, size, CV_16SC2, map1, map2) as called at
 // cameraCalibration/methods/methods.cpp:1705-1706: per destination pixel back-project through
 // inv(P[:3,:3] * R) (accumulated incrementally along the row), apply the
@@ -42,15 +55,9 @@ static inline int round_sat_i32(double v)
 extern "C" int mdisp_build_rectify_maps(const double K[9], const double* dist, int ndist, const double R[9],
                                         const double P[12], int width, int height, int16_t* map1, uint16_t* map2)
 {
-    MD_REQUIRE(K && R && P && map1 && map2 && width > 0 && height > 0, MDISP_E_BADARG, "null argument or empty size");
-    MD_REQUIRE(ndist == 0 || dist, MDISP_E_BADARG, "null distortion vector");
-    MD_REQUIRE(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8, MDISP_E_BADARG, "distortion vector must have 0, 4, 5 or 8 entries");
-    const double Ar[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
-    double ArR[9], ir[9];
-    mul33(Ar, R, ArR);
-    MD_REQUIRE(inv33(ArR, ir), MDISP_E_BADARG, "P[:3,:3]*R is singular");
-    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < ndist; i++) k[i] = dist[i];
+    MD_REQUIRE(map1 && map2 && width > 0 && height > 0, MDISP_E_BADARG, "null argument or empty size");
+    double ir[9], k[8];
+    MD_TRY(md_rectify_map_setup(K, dist, ndist, R, P, ir, k));
     const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
     const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
     for (int i = 0; i < height; i++) {

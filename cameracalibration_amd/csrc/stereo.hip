@@ -344,6 +344,46 @@ int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, co
     return MDISP_OK;
 }
 
+// cv::initUndistortRectifyMap(..., CV_16SC2, map1, map2) on the device: one thread per destination row,
+// walking the row with the library's incremental sums (_x += ir[0] ...), so that every map entry
+// equals the host construction bit for bit (double arithmetic, no contraction).
+struct MapArgs { double ir[9], k[8], fx, fy, u0, v0; int W, H; int16_t* m1; u16* m2; };
+__global__ __launch_bounds__(64) void rectify_maps_kernel(MapArgs a)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.H) return;
+    const double k1 = a.k[0], k2 = a.k[1], p1 = a.k[2], p2 = a.k[3], k3 = a.k[4], k4 = a.k[5], k5 = a.k[6], k6 = a.k[7];
+    double _x = i * a.ir[1] + a.ir[2], _y = i * a.ir[4] + a.ir[5], _w = i * a.ir[7] + a.ir[8];
+    for (int j = 0; j < a.W; j++, _x += a.ir[0], _y += a.ir[3], _w += a.ir[6]) {
+        const double w = 1. / _w, x = _x * w, y = _y * w;
+        const double x2 = x * x, y2 = y * y;
+        const double r2 = x2 + y2, _2xy = 2 * x * y;
+        const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+        const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2));
+        const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy);
+        double u = (a.fx * xd + a.u0) * 32, v = (a.fy * yd + a.v0) * 32;
+        u = fmin(fmax(u, -2147483648.0), 2147483647.0);
+        v = fmin(fmax(v, -2147483648.0), 2147483647.0);
+        const int iu = (int)rint(u), iv = (int)rint(v);        // round half to even, as cvRound
+        const size_t o = (size_t)i * a.W + j;
+        a.m1[o * 2] = (int16_t)(iu >> 5);
+        a.m1[o * 2 + 1] = (int16_t)(iv >> 5);
+        a.m2[o] = (u16)((iv & 31) * 32 + (iu & 31));
+    }
+}
+
+int md_rectify_maps(hipStream_t s, const double ir[9], const double k[8], double fx, double fy, double u0, double v0, int W, int H,
+                    int16_t* m1, u16* m2)
+{
+    MapArgs a;
+    for (int i = 0; i < 9; i++) a.ir[i] = ir[i];
+    for (int i = 0; i < 8; i++) a.k[i] = k[i];
+    a.fx = fx; a.fy = fy; a.u0 = u0; a.v0 = v0; a.W = W; a.H = H; a.m1 = m1; a.m2 = m2;
+    rectify_maps_kernel<<<(H + 63) / 64, 64, 0, s>>>(a);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Disparity -> 3-D points (cameraCalibration/methods/methods.cpp:2039-2076 and :2300-2352), double
 // arithmetic per pixel, float output (x, y, z interleaved as in pcl::PointXYZ).

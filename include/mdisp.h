@@ -260,6 +260,21 @@ int mdisp_stereo_rectify(const double K1[9], const double* D1, const double K2[9
  * src/dst CV_8UC1 or CV_8UC3; maps as produced above, of dst's size. */
 int mdisp_remap(mdisp_ctx*, const mdisp_image* src, const int16_t* map1, const uint16_t* map2, mdisp_image* dst);
 
+/* Device-resident maps of cv::initUndistortRectifyMap(K, D, R, P, size, CV_16SC2, ...) (methods/methods.cpp:1705-1706),
+ * built ON THE GPU once per calibration and reused for every frame (mdisp_remap uploads host maps on every call).
+ * Entries are bit-identical to mdisp_build_rectify_maps. */
+typedef struct mdisp_rectify_maps mdisp_rectify_maps;
+int  mdisp_rectify_maps_create(mdisp_ctx*, const double K[9], const double* dist, int ndist, const double R[9],
+                               const double P[12], int width, int height, mdisp_rectify_maps** maps);
+void mdisp_rectify_maps_destroy(mdisp_rectify_maps* maps);
+int  mdisp_rectify_maps_download(mdisp_ctx*, const mdisp_rectify_maps* maps, int16_t* map1, uint16_t* map2);
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) (methods/methods.cpp:1709-1710) with such maps: host images ... */
+int  mdisp_remap_with(mdisp_ctx*, const mdisp_rectify_maps* maps, const mdisp_image* src, mdisp_image* dst);
+/* ... and device-resident interleaved 8-bit images (no copies, no sync); dst has the size of the maps. */
+int  mdisp_remap_dev(mdisp_ctx*, const mdisp_rectify_maps* maps, const uint8_t* d_src, size_t src_pitch, int src_rows, int src_cols,
+                     int channels, uint8_t* d_dst, size_t dst_pitch);
+
+
 /* Disparity -> 3-D points, the step downstream of the disparity routines.
  * mdisp_reproject_q: methods/methods.cpp:2039-2076 -- [X Y Z W] = Q * [row col d 1] (row index first, as the
  *   reference writes it), point = (X/W, Y/W, Z/W) / 100; zero where the disparity is 0.

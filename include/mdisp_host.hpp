@@ -320,18 +320,35 @@ template <class M> void lrCheck(M dispL, M dispR, float thresh, M& validL, M& va
     detail::check(mdisp_lr_check(Context::forThisThread().handle(), &a, &b, thresh, &vl, &vr));
 }
 
-// the rectification step of getRectifiedImages (methods/methods.cpp:1705-1745): maps on the host in
-// double precision, remap on the GPU.  K, dist, R, P are row-major.
+// The maps of initUndistortRectifyMap (methods/methods.cpp:1705-1706) kept on the device: built once per
+// calibration (on the GPU, double precision), then `remap` = cv::remap(src, dst, map1, map2, INTER_LINEAR) per frame.
+class RectifyMaps {
+public:
+    RectifyMaps(const double K[9], const double* dist, int ndist, const double R[9], const double P[12], int width, int height)
+    { detail::check(mdisp_rectify_maps_create(Context::forThisThread().handle(), K, dist, ndist, R, P, width, height, &maps_)); }
+    ~RectifyMaps() { mdisp_rectify_maps_destroy(maps_); }
+    RectifyMaps(const RectifyMaps&) = delete;
+    RectifyMaps& operator=(const RectifyMaps&) = delete;
+    template <class M> void remap(M src, M& dst, int width, int height) const
+    {
+        typedef mat_traits<M> T;
+        mdisp_image s = T::view(src);
+        T::create(dst, height, width, MDISP_8U, s.channels);
+        mdisp_image d = T::view(dst);
+        detail::check(mdisp_remap_with(Context::forThisThread().handle(), maps_, &s, &d));
+    }
+private:
+    mdisp_rectify_maps* maps_ = nullptr;
+};
+
+// the rectification step of getRectifiedImages (methods/methods.cpp:1705-1745): maps and remap on the GPU.
+// K, dist, R, P are row-major.
 template <class M> void rectifyImage(M src, const double K[9], const double* dist, int ndist, const double R[9], const double P[12], M& dst)
 {
     typedef mat_traits<M> T;
     mdisp_image s = T::view(src);
-    std::vector<int16_t> m1((size_t)s.rows * s.cols * 2);
-    std::vector<uint16_t> m2((size_t)s.rows * s.cols);
-    detail::check(mdisp_build_rectify_maps(K, dist, ndist, R, P, s.cols, s.rows, m1.data(), m2.data()));
-    T::create(dst, s.rows, s.cols, MDISP_8U, s.channels);
-    mdisp_image d = T::view(dst);
-    detail::check(mdisp_remap(Context::forThisThread().handle(), &s, m1.data(), m2.data(), &d));
+    RectifyMaps maps(K, dist, ndist, R, P, s.cols, s.rows);
+    maps.remap(src, dst, s.cols, s.rows);
 }
 
 // disparity -> 3-D points (methods/methods.cpp:2039-2076 and :2300-2352); xyz is CV_32FC3

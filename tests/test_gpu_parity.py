@@ -318,3 +318,34 @@ def test_sgm_host_batch_streams_chunks(api, orc, n, chunk, W):
     assert got.shape == (n, H, W)
     for i in range(n):
         assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], 0, D, 8, 32, 10, 1, 8, 1))
+
+
+@pytest.mark.gpu
+def test_rectification_maps_built_on_the_gpu(api, orc):
+    # device-resident maps: every entry equals the host construction and the oracle, at a small size with all eight
+    # distortion terms and at the calibrated 2560x1440 camera of the reference (unditortStereoCalib.xml values)
+    import json
+    import os
+    rng = np.random.default_rng(23)
+    K = np.array([[80.0, 0, 29.5], [0, 81.0, 19.5], [0, 0, 1]])
+    ang = 0.03
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    P = np.array([[75.0, 0, 31.0, 0], [0, 75.0, 21.0, 0], [0, 0, 1, 0]])
+    for dist in (np.zeros(0), np.array([-0.2, 0.05, 0.001, -0.002]), np.array([-0.2, 0.05, 0.001, -0.002, 0.01]),
+                 np.array([-0.2, 0.05, 0.001, -0.002, 0.01, 0.02, -0.01, 0.003])):
+        maps = api.RectifyMaps(K, dist, R, P, (61, 43))
+        g1, g2 = maps.download()
+        h1, h2 = api.initUndistortRectifyMap(K, dist, R, P, (61, 43))
+        o1, o2 = orc.init_undistort_rectify_map(K, dist, R, P, (61, 43))
+        assert np.array_equal(g1, h1) and np.array_equal(g2, h2)
+        assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+        for shape in ((40, 60), (40, 60, 3)):
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+            assert np.array_equal(maps.remap(img), orc.remap(img, o1, o2))
+        maps.close()
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stereo_rectify_2560x1440.json")))
+    m = {k: (np.array(v["data"]).reshape(v["rows"], v["cols"]) if isinstance(v, dict) else v) for k, v in g.items()}
+    maps = api.RectifyMaps(m["StereoCalib_K1"], m["StereoCalib_D1"], m["Rectify_R1"], m["Rectify_P1"], (2560, 1440))
+    g1, g2 = maps.download()
+    h1, h2 = api.initUndistortRectifyMap(m["StereoCalib_K1"], m["StereoCalib_D1"], m["Rectify_R1"], m["Rectify_P1"], (2560, 1440))
+    assert np.array_equal(g1, h1) and np.array_equal(g2, h2)
