@@ -204,12 +204,33 @@ def asw_gifs(param, eps, gifType=GIF, r2=5, namda=0.1, h=0.5, cost_source=COST_C
 
 
 def asw_gifs_band_dev(d_left, d_right, rows, cols, pitch, winSize, minDisparity, maxDisparity, isDispLeft, eps, gifType, r2, namda,
-                      row_begin, row_end, d_disp, cost_source=COST_CENSUS, ctx=None):
+                      row_begin, row_end, d_disp, cost_source=COST_CENSUS, ctx=None, stats=None):
     """asw_gifs on device-resident images (raw device pointers), output rows [row_begin, row_end) only:
-    one GPU's share of a pair that is sharded by horizontal row bands.  d_disp: float32 rows x cols."""
+    one GPU's share of a pair that is sharded by horizontal row bands.  d_disp: float32 rows x cols.
+    stats: (cost_minmax, steer_max) merged over all bands (asw_gifs_band_stats_dev + element-wise min / max), or
+    None to recompute the image-wide statistics locally."""
     p = mdisp_param(winSize, minDisparity, maxDisparity, 1 if isDispLeft else 0)
+    mm = sm = None
+    if stats is not None:
+        mm = np.ascontiguousarray(stats[0], dtype=np.float32).reshape(-1)
+        if mm.size != 2 * (maxDisparity - minDisparity + 1):
+            raise ValueError("cost_minmax must hold (min, max) for every disparity")
+        sm = C.c_double(float(stats[1]))
     check(load().mdisp_asw_gifs_band_dev(_ctx(ctx), d_left, d_right, rows, cols, pitch, C.byref(p), eps, gifType, r2, namda,
-                                         cost_source, row_begin, row_end, d_disp))
+                                         cost_source, row_begin, row_end, d_disp, mm.ctypes.data if mm is not None else None,
+                                         C.byref(sm) if sm is not None else None))
+
+
+def asw_gifs_band_stats_dev(d_left, d_right, rows, cols, pitch, winSize, minDisparity, maxDisparity, isDispLeft, gifType,
+                            row_begin, row_end, cost_source=COST_CENSUS, ctx=None):
+    """One band's share of the image-wide statistics of asw_gifs: (cost_minmax float32 [numDisp, 2], steer_max float)."""
+    p = mdisp_param(winSize, minDisparity, maxDisparity, 1 if isDispLeft else 0)
+    D = maxDisparity - minDisparity + 1
+    mm = np.empty((D, 2), dtype=np.float32)
+    sm = C.c_double(0.0)
+    check(load().mdisp_asw_gifs_band_stats_dev(_ctx(ctx), d_left, d_right, rows, cols, pitch, C.byref(p), gifType, cost_source,
+                                               row_begin, row_end, mm.ctypes.data, C.byref(sm)))
+    return mm, sm.value
 
 
 def sgbm_params(minDisparity=0, numDisparities=64, P1=0, P2=0, uniquenessRatio=-1, disp12MaxDiff=0, paths=8,

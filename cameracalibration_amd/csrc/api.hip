@@ -494,11 +494,12 @@ extern "C" int mdisp_asw_gifs(mdisp_ctx* c, const mdisp_image* L, const mdisp_im
 // when a large pair is sharded by row bands.  Both full images are resident on every GPU; everything
 // that is global to the image (guide statistics, steer weights, per-slice cost ranges) is recomputed
 // locally from them, so the bands need no exchange and are bit-identical to the rows of a full call.
-extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
-                                       const mdisp_param* p, double eps, int gif_type, int r2, double namda, int cost_source,
-                                       int row_begin, int row_end, float* d_disp)
+struct BandSetup { const u8 *ref, *cr, *cp; size_t crp, cpp; int kind, off0, offStep, H, W, D, minD; void* gif; };
+// checks + the full-image preliminaries every band needs (padded other view, census codes of both views)
+static int band_setup(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch, const mdisp_param* p,
+                      int gif_type, int cost_source, int row_begin, int row_end, BandSetup* b)
 {
-    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(c && d_left && d_right && p, MDISP_E_BADARG, "null argument");
     MD_REQUIRE(rows > 0 && cols > 0 && pitch >= (size_t)cols && pitch % 4 == 0, MDISP_E_BADARG,
                "bad geometry (pitch must be a multiple of 4 and >= cols)");
     MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0 && p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity,
@@ -506,8 +507,7 @@ extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     MD_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= rows, MDISP_E_BADARG, "bad row band [%d, %d)", row_begin, row_end);
     MD_REQUIRE(gif_type >= MDISP_GIF && gif_type <= MDISP_OURS_GIF3, MDISP_E_BADARG, "unknown GIF type %d", gif_type);
     MD_REQUIRE(cost_source == MDISP_COST_CENSUS || cost_source == MDISP_COST_ABSDIFF, MDISP_E_BADARG,
-               "the band entry point forms its cost slices on the device (census or absdiff)");
-    if (row_begin == row_end) return MDISP_OK;
+               "the band entry points form their cost slices on the device (census or absdiff)");
     MD_HIP(hipSetDevice(c->device));
     const int H = rows, W = cols, maxD = p->maxDisparity, minD = p->minDisparity, D = maxD - minD + 1, Wp = W + maxD;
     const size_t pitchP = md_align(Wp, 256);
@@ -523,17 +523,40 @@ extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     if (p->isDispLeft) rc = md_pad_reflect_lr(s, other, pitch, H, W, maxD, 0, base + o_pad, pitchP);
     else rc = md_pad_reflect_lr(s, other, pitch, H, W, 0, maxD, base + o_pad, pitchP);
     if (rc) return rc;
-    const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
-    const u8 *cr, *cp; size_t crp, cpp; int kind;
+    b->off0 = p->isDispLeft ? (maxD - minD) : minD; b->offStep = p->isDispLeft ? -1 : 1;
     if (cost_source == MDISP_COST_CENSUS) {
         if ((rc = md_census(s, ref, pitch, H, W, MDISP_BASIC_CENSUS, 0, base + o_cr, pitchP, base + o_scr))) return rc;
         if ((rc = md_census(s, base + o_pad, pitchP, H, Wp, MDISP_BASIC_CENSUS, 0, base + o_cp, pitchP, base + o_scr))) return rc;
-        cr = base + o_cr; crp = pitchP; cp = base + o_cp; cpp = pitchP; kind = MD_COST_HAMMING;
+        b->cr = base + o_cr; b->crp = pitchP; b->cp = base + o_cp; b->cpp = pitchP; b->kind = MD_COST_HAMMING;
     } else {
-        cr = ref; crp = pitch; cp = base + o_pad; cpp = pitchP; kind = MD_COST_ABSDIFF;
+        b->cr = ref; b->crp = pitch; b->cp = base + o_pad; b->cpp = pitchP; b->kind = MD_COST_ABSDIFF;
     }
-    return md_gif_stereo(c, base + o_gif, ref, pitch, H, W, D, minD, p->winSize, eps, gif_type, r2, namda, cr, crp, cp, cpp, off0, offStep,
-                         kind, nullptr, 0, d_disp, nullptr, row_begin, row_end);
+    b->ref = ref; b->H = H; b->W = W; b->D = D; b->minD = minD; b->gif = base + o_gif;
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_asw_gifs_band_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                       const mdisp_param* p, double eps, int gif_type, int r2, double namda, int cost_source,
+                                       int row_begin, int row_end, float* d_disp, const float* cost_minmax, const double* steer_max)
+{
+    MD_REQUIRE(d_disp, MDISP_E_BADARG, "null argument");
+    BandSetup b;
+    MD_TRY(band_setup(c, d_left, d_right, rows, cols, pitch, p, gif_type, cost_source, row_begin, row_end, &b));
+    if (row_begin == row_end) return MDISP_OK;
+    return md_gif_stereo(c, b.gif, b.ref, pitch, b.H, b.W, b.D, b.minD, p->winSize, eps, gif_type, r2, namda, b.cr, b.crp, b.cp, b.cpp,
+                         b.off0, b.offStep, b.kind, nullptr, 0, d_disp, nullptr, row_begin, row_end, cost_minmax,
+                         gif_type == MDISP_SKWGIF ? steer_max : nullptr);
+}
+
+extern "C" int mdisp_asw_gifs_band_stats_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                             const mdisp_param* p, int gif_type, int cost_source, int row_begin, int row_end,
+                                             float* cost_minmax, double* steer_max)
+{
+    MD_REQUIRE(cost_minmax && steer_max, MDISP_E_BADARG, "null argument");
+    BandSetup b;
+    MD_TRY(band_setup(c, d_left, d_right, rows, cols, pitch, p, gif_type, cost_source, row_begin, row_end, &b));
+    return md_gif_band_stats(c, b.gif, b.ref, pitch, b.H, b.W, b.D, gif_type, b.cr, b.crp, b.cp, b.cpp, b.off0, b.offStep, b.kind,
+                             row_begin, row_end, cost_minmax, steer_max);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -142,7 +142,11 @@ size_t md_gif_scratch_bytes(int H, int W, int D);
 int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
                   int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
                   int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64,
-                  int yA = -1, int yB = -1 /* output rows [yA, yB); default: the whole image */);
+                  int yA = -1, int yB = -1 /* output rows [yA, yB); default: the whole image */,
+                  const float* extMinMax = nullptr, const double* extSteerMax = nullptr /* image-wide statistics, host memory */);
+int md_gif_band_stats(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int gif_type,
+                      const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep, int costKind, int yA, int yB,
+                      float* minmax, double* steerMax);
 
 // cost kinds of md_cost_box_wta
 enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };

@@ -75,12 +75,12 @@ __device__ __forceinline__ int raw_cost(const CostSrc& c, int x, int y, int k)
 // 256 columns x MM_ROWS rows and walks the slices with the tile's reference pixels in registers, so
 // each census / gray byte is fetched once and the shifted operand rows stay in cache.
 #define MM_ROWS 16
-__global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, int n, u32* __restrict__ part)
+__global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, int n, u32* __restrict__ part, int yBeg, int yEnd)
 {
     __shared__ u32 slo[4], shi[4];
-    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * MM_ROWS;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = yBeg + blockIdx.y * MM_ROWS;
     const bool inx = x < c.W;
-    const int rows = min(MM_ROWS, c.H - y0);
+    const int rows = min(MM_ROWS, yEnd - y0);
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     int ref[MM_ROWS];
 #pragma unroll
@@ -178,10 +178,11 @@ __global__ __launch_bounds__(256) void minmax_u8_image_kernel(const u8* __restri
 #define BH_SEG 1024   // outputs per workgroup along x
 // out[k][y][x] = sum over the window of A[k][y][.] (times B[.][y][.], rounded to float first, when B != null)
 __global__ __launch_bounds__(256) void box_h_kernel(const float* __restrict__ A, size_t aStride, const float* __restrict__ B,
-                                                    size_t bStride, int H, int W, int ksz, int mode, double* __restrict__ out)
+                                                    size_t bStride, int H, int W, int ksz, int mode, double* __restrict__ out,
+                                                    int yOff = 0)
 {
     extern __shared__ float seg[];   // BH_SEG + ksz values
-    const int y = blockIdx.y, k = blockIdx.z, x0 = blockIdx.x * BH_SEG;
+    const int y = yOff + blockIdx.y, k = blockIdx.z, x0 = blockIdx.x * BH_SEG;
     const int ax = ksz / 2;
     const float* a = A + (size_t)k * aStride + (size_t)y * W;
     const float* b = B ? B + (size_t)k * bStride + (size_t)y * W : nullptr;
@@ -237,9 +238,9 @@ __global__ __launch_bounds__(256) void box_v_kernel(const double* __restrict__ i
 
 // same vertical pass but keeping the double sum (used for the steer-weight normaliser)
 __global__ __launch_bounds__(256) void box_v_f64_kernel(const double* __restrict__ in, int H, int W, int ksz, int mode,
-                                                        double* __restrict__ out)
+                                                        double* __restrict__ out, int yBeg, int yEnd)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * BV_SEG;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = yBeg + blockIdx.y * BV_SEG;
     if (x >= W) return;
     const int ay = ksz / 2;
     const int taps = mode == 0 ? ksz : 2 * ay;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void box_v_f64_kernel(const double* __restrict
     for (int i = 0; i < taps; i++) s += tap(y0 - ay + i);
     for (int j = 0; j < BV_SEG; j++) {
         const int y = y0 + j;
-        if (y >= H) break;
+        if (y >= yEnd) break;
         if (j > 0) s += tap(y - 1 - ay + taps) - tap(y - 1 - ay);
         out[(size_t)y * W + x] = s;
     }
@@ -742,12 +743,13 @@ __device__ __forceinline__ int reflect_b(int p, int n)   // BORDER_REFLECT
 // as an ordered-bits atomicMax (the values are non-negative doubles).
 __global__ __launch_bounds__(ST_T * ST_T) void steer_strength_kernel(const u8* __restrict__ src, size_t sp, int H, int W,
                                                                      const SteerTaps* __restrict__ taps,
-                                                                     double* __restrict__ O, unsigned long long* __restrict__ maxbits)
+                                                                     double* __restrict__ O, unsigned long long* __restrict__ maxbits,
+                                                                     int yBeg, int yEnd)
 {
     __shared__ float tile[ST_T + 10][ST_T + 10];
     __shared__ double kk[7][121];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int x0 = blockIdx.x * ST_T, y0 = blockIdx.y * ST_T;
+    const int x0 = blockIdx.x * ST_T, y0 = yBeg + blockIdx.y * ST_T;
     for (int i = ty * ST_T + tx; i < 7 * 121; i += ST_T * ST_T) kk[i / 121][i % 121] = taps->k[i / 121][i % 121];
     for (int i = ty * ST_T + tx; i < (ST_T + 10) * (ST_T + 10); i += ST_T * ST_T) {
         const int ry = i / (ST_T + 10), rx = i % (ST_T + 10);
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(ST_T * ST_T) void steer_strength_kernel(const u8* _
     __syncthreads();
     const int x = x0 + tx, y = y0 + ty;
     double v = 0.0;
-    if (x < W && y < H) {
+    if (x < W && y < yEnd) {
         double s[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < 11; k++)
             for (int j = 0; j < 11; j++) {
@@ -788,11 +790,11 @@ __global__ __launch_bounds__(ST_T * ST_T) void steer_strength_kernel(const u8* _
 }
 
 // dst = clamp(O / max * 255, 1e-6, 120) with the reference's comparison order (:412, :434-441)
-__global__ __launch_bounds__(256) void steer_scale_kernel(const double* __restrict__ O, size_t N, const unsigned long long* maxbits,
+__global__ __launch_bounds__(256) void steer_scale_kernel(const double* __restrict__ O, size_t i0, size_t i1, const unsigned long long* maxbits,
                                                           double* __restrict__ dst, float* __restrict__ dstf)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    const size_t i = i0 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= i1) return;
     const double mx = __longlong_as_double((long long)*maxbits);
     double v = __dmul_rn(__ddiv_rn(__dmul_rn(O[i], 1.0), mx), 255.0);
     if (v > 120) v = 120;
@@ -810,9 +812,14 @@ static double G2c(int x, int y) { double xs = x * x, ys = y * y; xs = exp(-(xs +
 static double H2d(int x, int y) { double xs = pow(x, 2), ys = pow(y, 2); xs = exp(-(xs + ys)); return 0.9780 * (-2.254 * y + y * ys) * xs; }
 
 // O, maxbits, tapsDev: device scratch (N doubles, 8 bytes, sizeof(SteerTaps)); dst / dstf may be null
+// Rows [yBeg, yEnd) only (yBeg < 0: the whole image).  extMax (host, nullable): the global maximum of the
+// orientation strength when the caller already knows it (row-band sharding: the maximum over all bands);
+// scaleToo = false stops after the strength pass (maxbits then holds the maximum over the rows computed).
 static int steer_run(hipStream_t s, const u8* src, size_t sp, int H, int W, double* O, unsigned long long* maxbits,
-                     SteerTaps* tapsDev, double* dst, float* dstf)
+                     SteerTaps* tapsDev, double* dst, float* dstf, int yBeg = -1, int yEnd = -1, const double* extMax = nullptr,
+                     bool scaleToo = true)
 {
+    if (yBeg < 0) { yBeg = 0; yEnd = H; }
     static SteerTaps host;   // basis kernels, steerFilter.cpp:283-293 (filled once; read-only afterwards)
     static bool filled = false;
     if (!filled) {
@@ -825,11 +832,16 @@ static int steer_run(hipStream_t s, const u8* src, size_t sp, int H, int W, doub
         filled = true;
     }
     MD_HIP(hipMemcpyAsync(tapsDev, &host, sizeof(SteerTaps), hipMemcpyHostToDevice, s));
-    MD_HIP(hipMemsetAsync(maxbits, 0, 8, s));
-    dim3 grid((W + ST_T - 1) / ST_T, (H + ST_T - 1) / ST_T), block(ST_T, ST_T);
-    steer_strength_kernel<<<grid, block, 0, s>>>(src, sp, H, W, tapsDev, O, maxbits);
-    const size_t N = (size_t)H * W;
-    steer_scale_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(O, N, maxbits, dst, dstf);
+    // the strengths are non-negative doubles: their bit patterns order like the values, and starting the running
+    // maximum at the known global maximum leaves it there
+    if (extMax) MD_HIP(hipMemcpyAsync(maxbits, extMax, 8, hipMemcpyHostToDevice, s));
+    else MD_HIP(hipMemsetAsync(maxbits, 0, 8, s));
+    if (yEnd > yBeg) {
+        dim3 grid((W + ST_T - 1) / ST_T, (yEnd - yBeg + ST_T - 1) / ST_T), block(ST_T, ST_T);
+        steer_strength_kernel<<<grid, block, 0, s>>>(src, sp, H, W, tapsDev, O, maxbits, yBeg, yEnd);
+        const size_t i0 = (size_t)yBeg * W, i1 = (size_t)yEnd * W;
+        if (scaleToo) steer_scale_kernel<<<(unsigned)((i1 - i0 + 255) / 256), 256, 0, s>>>(O, i0, i1, maxbits, dst, dstf);
+    }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }
@@ -917,9 +929,14 @@ static float gauss3_const(float c)
     return s;
 }
 
+// [wA, wB): the rows of the steer weights that are valid in steerW_dev and that the caller's output rows need
+// (the whole image by default)
 static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, int W, int r, int r2, int type, double eps,
-                         double namuda, const double* steerW_dev, GifScratch& sc, GuideState& gs, Carve2& cv)
+                         double namuda, const double* steerW_dev, GifScratch& sc, GuideState& gs, Carve2& cv, int wA = -1, int wB = -1,
+                         int yA = -1, int yB = -1)
 {
+    if (wA < 0) { wA = 0; wB = H; }
+    if (yA < 0) { yA = 0; yB = H; }
     hipStream_t s = c->stream;
     const size_t N = (size_t)H * W;
     gs.H = H; gs.W = W; gs.r = r; gs.r2 = r2; gs.type = type;
@@ -999,12 +1016,13 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
         if (type == MDISP_SKWGIF) {
         // steer weights: float copy (gifs.cpp:574-577) and their clipped-window sum (:600)
         gs.w = cv.take<float>(N); gs.wsum = cv.take<double>(N);
-        f64_to_f32_kernel<<<nblk(N), 256, 0, s>>>(steerW_dev, N, gs.w);
-        dim3 gh((W + BH_SEG - 1) / BH_SEG, H, 1);
-        box_h_kernel<<<gh, 256, (BH_SEG + r2 + 8) * sizeof(float), s>>>(gs.w, 0, nullptr, 0, H, W, r2, 1, sc.gd);
-        dim3 gv((W + 255) / 256, (H + BV_SEG - 1) / BV_SEG, 1);
+        const size_t w0 = (size_t)wA * W, wn = (size_t)(wB - wA) * W;
+        f64_to_f32_kernel<<<nblk(wn), 256, 0, s>>>(steerW_dev + w0, wn, gs.w + w0);
+        dim3 gh((W + BH_SEG - 1) / BH_SEG, wB - wA, 1);
+        box_h_kernel<<<gh, 256, (BH_SEG + r2 + 8) * sizeof(float), s>>>(gs.w, 0, nullptr, 0, H, W, r2, 1, sc.gd, wA);
+        dim3 gv((W + 255) / 256, (yB - yA + BV_SEG - 1) / BV_SEG, 1);
         double* hs2 = cv.take<double>(N);
-        box_v_f64_kernel<<<gv, 256, 0, s>>>(sc.gd, H, W, r2, 1, hs2);
+        box_v_f64_kernel<<<gv, 256, 0, s>>>(sc.gd, H, W, r2, 1, hs2, yA, yB);
         gs.wsum = hs2;
         }
     } else {
@@ -1185,12 +1203,61 @@ size_t md_gif_scratch_bytes(int H, int W, int D)
 {
     const size_t N = (size_t)H * W;
     const int n = pick_batch(N, D);
-    return gif_scratch_bytes(N, n) + guide_extra_bytes(N) + md_align(N * 8, 256) * 3 + md_align(N * 4, 256) * 2 + 16384;
+    return gif_scratch_bytes(N, n) + guide_extra_bytes(N) + md_align(N * 8, 256) * 3 + md_align(N * 4, 256) * 2 + 16384 +
+           md_align((size_t)D * 8, 256);
 }
 
+static inline u32 f2ord_host(float f) { u32 u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+static inline float ord2f_host(u32 o) { u32 u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o; float f; memcpy(&f, &u, 4); return f; }
+
+// One band's share of the statistics that span the whole image: per-slice min / max of the integer cost over rows
+// [yA, yB) (minmax[2k], minmax[2k+1]; +FLT_MAX / -FLT_MAX for an empty band) and, for SKWGIF, the maximum of the
+// steer filter's orientation strength over the same rows.  Synchronises the stream (results go to host memory).
+int md_gif_band_stats(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int gif_type,
+                      const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep, int costKind, int yA, int yB,
+                      float* minmax, double* steerMax)
+{
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)H * W;
+    const int n = pick_batch(N, D);
+    Carve2 cv{(u8*)scratch};
+    GifScratch sc; scratch_carve(cv, N, n, sc);
+    (void)cv.take<float>(N);
+    double* O = cv.take<double>(N);
+    for (int k = 0; k < D; k++) { minmax[2 * k] = FLT_MAX; minmax[2 * k + 1] = -FLT_MAX; }
+    if (steerMax) *steerMax = 0.0;
+    if (yB <= yA) return MDISP_OK;
+    int rc;
+    if (gif_type == MDISP_SKWGIF && steerMax) {
+        if ((rc = steer_run(s, dGuide, gpitch, H, W, O, sc.maxbits, sc.taps, nullptr, nullptr, yA, yB, nullptr, false))) return rc;
+        MD_HIP(hipMemcpyAsync(steerMax, sc.maxbits, 8, hipMemcpyDeviceToHost, s));
+    }
+    CostSrc cs;
+    cs.ref = ref; cs.rp = rp; cs.pad = pad; cs.pp = pp; cs.W = W; cs.H = H; cs.off0 = off0; cs.offStep = offStep; cs.kind = costKind;
+    std::vector<u32> h(2 * (size_t)n);
+    for (int k0 = 0; k0 < D; k0 += n) {
+        const int nb = D - k0 < n ? D - k0 : n;
+        mm_init_kernel<<<(nb + 63) / 64, 64, 0, s>>>(sc.mm + 2, nb);
+        const dim3 gm((W + 255) / 256, (yB - yA + MM_ROWS - 1) / MM_ROWS);
+        u32* part = reinterpret_cast<u32*>(sc.T);
+        cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part, yA, yB);
+        cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
+        MD_HIP(hipGetLastError());
+        MD_HIP(hipMemcpyAsync(h.data(), sc.mm + 2, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+        MD_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < nb; k++) { minmax[2 * (k0 + k)] = ord2f_host(h[2 * k]); minmax[2 * (k0 + k) + 1] = ord2f_host(h[2 * k + 1]); }
+    }
+    MD_HIP(hipStreamSynchronize(s));
+    return MDISP_OK;
+}
+
+// extMinMax (host, 2*D floats, nullable) / extSteerMax (host, nullable): image-wide statistics the caller already
+// has (merged md_gif_band_stats results); when given, the per-slice cost range is not recomputed and the steer
+// filter runs on the rows the band needs only.
 int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, int H, int W, int D, int minD, int r, double eps,
                   int gif_type, int r2, double namuda, const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep,
-                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64, int yA, int yB)
+                  int costKind, const float* hostCosts, int normMode, float* dDisp32, double* dDisp64, int yA, int yB,
+                  const float* extMinMax, const double* extSteerMax)
 {
     hipStream_t s = c->stream;
     if (yA < 0) { yA = 0; yB = H; }
@@ -1201,12 +1268,24 @@ int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, 
     float* best = cv.take<float>(N);
     double* O = cv.take<double>(N); double* steerD = cv.take<double>(N);
     int rc;
+    int wA = 0, wB = H;
     if (gif_type == MDISP_SKWGIF) {
         // asw_gifs computes the weights from the gray guide once (methods_disp.cpp:1176-1180)
-        if ((rc = steer_run(s, dGuide, gpitch, H, W, O, sc.maxbits, sc.taps, steerD, nullptr))) return rc;
+        if (extSteerMax) {
+            wA = yA - r2 < 0 ? 0 : yA - r2; wB = yB + r2 > H ? H : yB + r2;
+            if ((rc = steer_run(s, dGuide, gpitch, H, W, O, sc.maxbits, sc.taps, steerD, nullptr, wA, wB, extSteerMax))) return rc;
+        } else if ((rc = steer_run(s, dGuide, gpitch, H, W, O, sc.maxbits, sc.taps, steerD, nullptr))) return rc;
     }
     GuideState gs;
-    if ((rc = guide_prepare(c, dGuide, gpitch, H, W, r, r2, gif_type, eps, namuda, steerD, sc, gs, cv))) return rc;
+    if ((rc = guide_prepare(c, dGuide, gpitch, H, W, r, r2, gif_type, eps, namuda, steerD, sc, gs, cv, wA, wB, yA, yB))) return rc;
+    u32* extDev = nullptr;       // the caller's per-slice cost ranges in the kernels' ordered-integer form
+    if (extMinMax && !hostCosts) {
+        std::vector<u32> extOrd(2 * (size_t)D);
+        for (int k = 0; k < 2 * D; k++) extOrd[k] = f2ord_host(extMinMax[k]);
+        extDev = cv.take<u32>(2 * (size_t)D);
+        MD_HIP(hipMemcpyAsync(extDev, extOrd.data(), extOrd.size() * 4, hipMemcpyHostToDevice, s));
+        MD_HIP(hipStreamSynchronize(s));      // extOrd leaves scope; nothing heavy has been enqueued yet
+    }
     CostSrc cs;
     cs.ref = ref; cs.rp = rp; cs.pad = pad; cs.pp = pp; cs.W = W; cs.H = H; cs.off0 = off0; cs.offStep = offStep; cs.kind = costKind;
     for (int k0 = 0; k0 < D; k0 += n) {
@@ -1219,11 +1298,13 @@ int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, 
             MD_HIP(hipMemcpyAsync(raw, hostCosts + (size_t)k0 * N, (size_t)nb * N * 4, hipMemcpyHostToDevice, s));
             minmax_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2);
             normalize_kernel<float><<<g, 256, 0, s>>>(raw, N, sc.mm + 2, NORM_FLOAT, sc.F0);
+        } else if (extDev) {
+            MD_HIP(hipMemcpyAsync(sc.mm + 2, extDev + 2 * (size_t)k0, (size_t)nb * 8, hipMemcpyDeviceToDevice, s));
         } else {
             // per-workgroup partials go through the (otherwise idle) double scratch
             const dim3 gm((W + 255) / 256, (H + MM_ROWS - 1) / MM_ROWS);
             u32* part = reinterpret_cast<u32*>(sc.T);
-            cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part);
+            cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part, 0, H);
             cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
         }
         if ((rc = gif_filter_batch(c, gs, sc, nb, hostCosts ? nullptr : &cs, k0, sc.mm + 2, normMode, nullptr, yA, yB))) return rc;

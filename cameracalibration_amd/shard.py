@@ -64,3 +64,21 @@ def gather_row_bands(band, rows, dist=None):
         b, e = row_band(rows, r, world)
         out.append(parts[r][:e - b])
     return torch.cat(out, dim=0)
+
+
+def merge_band_stats(cost_minmax, steer_max, dist=None, device="cpu"):
+    """Element-wise min of the per-slice minima, max of the maxima and of the steer maxima over all ranks: the one
+    (tiny) exchange of the row-band sharding.  cost_minmax: float32 [numDisp, 2]; returns the merged pair.  With
+    dist=None (single process) the inputs are returned unchanged."""
+    import numpy as np
+    mm = np.ascontiguousarray(cost_minmax, dtype=np.float32)
+    if dist is None:
+        return mm, float(steer_max)
+    import torch
+    lo = torch.from_numpy(mm[:, 0].copy()).to(device)
+    hi = torch.cat([torch.from_numpy(mm[:, 1].copy()).double(), torch.tensor([float(steer_max)], dtype=torch.float64)]).to(device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    hi = hi.cpu().numpy()
+    out = np.stack([lo.cpu().numpy(), hi[:-1].astype(np.float32)], axis=1)
+    return out, float(hi[-1])

@@ -317,12 +317,24 @@ int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_
 /* asw_gifs (methods_disp.h:66) on device buffers, restricted to the output rows [row_begin, row_end):
  * the share of one GPU when a large pair is split into horizontal row bands.  d_left / d_right hold
  * the WHOLE images (every GPU keeps a copy); d_disp is a float rows x cols map of which only the
- * band's rows are written.  Rows are bit-identical to those of a full-image call: every quantity
- * that is global to the image is recomputed locally, so bands need no exchange.  cost_source is
- * MDISP_COST_CENSUS or MDISP_COST_ABSDIFF. */
+ * band's rows are written.  Rows are bit-identical to those of a full-image call.  cost_source is
+ * MDISP_COST_CENSUS or MDISP_COST_ABSDIFF.
+ * cost_minmax (host, 2*numDisp floats: min, max per slice) and steer_max (host, one double) carry the
+ * statistics that span the whole image.  With NULL they are recomputed locally from the full images (no
+ * exchange at all, at the price of doing that part once per GPU); otherwise pass the element-wise min / max
+ * over all bands of what mdisp_asw_gifs_band_stats_dev returned (one small all-reduce), and the band computes
+ * only its own share. */
 int mdisp_asw_gifs_band_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                             const mdisp_param* p, double eps, int gif_type, int r2, double namda, int cost_source,
-                            int row_begin, int row_end, float* d_disp);
+                            int row_begin, int row_end, float* d_disp, const float* cost_minmax, const double* steer_max);
+
+/* One band's share of those statistics: per-slice min / max of the matching cost over rows [row_begin, row_end)
+ * (+FLT_MAX / -FLT_MAX for an empty band) and the maximum of the steer filter's orientation strength over the same
+ * rows (0 unless gif_type is MDISP_SKWGIF).  Results go to host memory; the call synchronises the stream.
+ * The reference computes these over the whole image (gifs.cpp:56, steerFilter.cpp:400-407). */
+int mdisp_asw_gifs_band_stats_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                  const mdisp_param* p, int gif_type, int cost_source, int row_begin, int row_end,
+                                  float* cost_minmax, double* steer_max);
 
 /* time of the most recent call's dominant kernel on this context, measured with HIP events on
  * the context's stream (milliseconds); which = 0: whole call, 1: SGM path aggregation (every scan

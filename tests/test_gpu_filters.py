@@ -173,3 +173,29 @@ def test_row_bands_equal_the_full_image(api, gif, win, r2):
     assert np.array_equal(full, api.asw_gifs(p, 0.01, gif, r2, 0.1, 0.5, api.COST_CENSUS))
     for bands in ([(0, 48), (48, 97)], [(0, 3), (3, 50), (50, 96), (96, 97)], [(0, 33), (33, 65), (65, 97)]):
         assert np.array_equal(run(bands), full)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gif,win,r2", [(0, 7, 5), (3, 9, 15), (2, 11, 5), (3, 35, 15), (6, 9, 15)])
+def test_row_bands_with_exchanged_statistics(api, gif, win, r2):
+    # each band computes its share of the image-wide statistics (per-slice cost range, steer maximum), the shares are
+    # merged (what the all-reduce of the multi-GPU run does), and the bands still reproduce the full image bit for bit
+    import torch
+    from cameracalibration_amd import shard
+    H, W, D = 97, 152, 24
+    L, R, _ = api.synth_pair(0x5EED0021, H, W, D)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=win, minDisparity=0, maxDisparity=D - 1, isDispLeft=True)
+    full = api.asw_gifs(p, 0.01, gif, r2, 0.1, 0.5, api.COST_CENSUS)
+    for bands in ([(0, 48), (48, 97)], [(0, 3), (3, 50), (50, 96), (96, 97)], [(0, 97), (97, 97)]):
+        parts = [api.asw_gifs_band_stats_dev(dl.data_ptr(), dr.data_ptr(), H, W, W, win, 0, D - 1, True, gif, b, e) for (b, e) in bands]
+        mm = np.stack([np.min([q[0][:, 0] for q in parts], axis=0), np.max([q[0][:, 1] for q in parts], axis=0)], axis=1)
+        sm = max(q[1] for q in parts)
+        one = shard.merge_band_stats(parts[0][0], parts[0][1])          # single process: unchanged
+        assert np.array_equal(one[0], parts[0][0]) and one[1] == parts[0][1]
+        out = torch.full((H, W), -1.0, dtype=torch.float32, device="cuda")
+        for (b, e) in bands:
+            api.asw_gifs_band_dev(dl.data_ptr(), dr.data_ptr(), H, W, W, win, 0, D - 1, True, 0.01, gif, r2, 0.1, b, e, out.data_ptr(),
+                                  stats=(mm, sm))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), full)

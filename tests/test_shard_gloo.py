@@ -111,3 +111,41 @@ def test_row_band_gather_two_ranks_gloo():
         assert p.exitcode == 0
     assert [r[1] for r in res] == [True, True]
     assert res[0][2] == (0, 6) and res[1][2] == (6, 11)
+
+
+def _stats_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 holds an empty band's sentinels in slice 1; rank 1 the larger steer maximum
+        big = np.finfo(np.float32).max
+        mine = np.array([[1.0, 5.0], [big, -big], [0.0, 3.0]], np.float32) if rank == 0 else \
+            np.array([[2.0, 7.0], [4.0, 6.0], [1.0, 2.0]], np.float32)
+        mm, sm = shard.merge_band_stats(mine, 10.5 + rank, dist)
+        q.put((rank, mm.tolist(), sm))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_statistics_merge_two_ranks_gloo():
+    # the only collective of the row-band sharding: min of minima, max of maxima (per slice) and of the steer maximum
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stats_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] == [[1.0, 7.0], [4.0, 6.0], [0.0, 3.0]]
+        assert r[2] == 11.5
