@@ -1097,7 +1097,7 @@ static void scratch_carve(Carve2& cv, size_t N, int n, GifScratch& sc)
 
 static int pick_batch(size_t N, int D)
 {
-    size_t budget = (size_t)3 << 30;                 // bytes of per-slice scratch (20 B per pixel per slice)
+    size_t budget = (size_t)16 << 30;                // bytes of per-slice scratch (20 B per pixel per slice): enough slices per launch to fill the GPU even when one band of a large image is processed
     size_t n = budget / (N * 20);
     if (n < 1) n = 1;
     if (n > (size_t)D) n = D;
