@@ -820,17 +820,18 @@ static int steer_run(hipStream_t s, const u8* src, size_t sp, int H, int W, doub
                      bool scaleToo = true)
 {
     if (yBeg < 0) { yBeg = 0; yEnd = H; }
-    static SteerTaps host;   // basis kernels, steerFilter.cpp:283-293 (filled once; read-only afterwards)
-    static bool filled = false;
-    if (!filled) {
+    // basis kernels, steerFilter.cpp:283-293: built once, thread-safely (the reference runs its left and right
+    // routines from two threads), read-only afterwards
+    static const SteerTaps host = [] {
+        SteerTaps t;
         for (int y = -5; y <= 5; y++)
             for (int x = -5; x <= 5; x++) {
                 const int i = (y + 5) * 11 + (x + 5);
-                host.k[0][i] = G2a(x, y); host.k[1][i] = G2b(x, y); host.k[2][i] = H2a(x, y); host.k[3][i] = H2b(x, y);
-                host.k[4][i] = G2c(x, y); host.k[5][i] = H2c(x, y); host.k[6][i] = H2d(x, y);
+                t.k[0][i] = G2a(x, y); t.k[1][i] = G2b(x, y); t.k[2][i] = H2a(x, y); t.k[3][i] = H2b(x, y);
+                t.k[4][i] = G2c(x, y); t.k[5][i] = H2c(x, y); t.k[6][i] = H2d(x, y);
             }
-        filled = true;
-    }
+        return t;
+    }();
     MD_HIP(hipMemcpyAsync(tapsDev, &host, sizeof(SteerTaps), hipMemcpyHostToDevice, s));
     // the strengths are non-negative doubles: their bit patterns order like the values, and starting the running
     // maximum at the known global maximum leaves it there
