@@ -17,12 +17,16 @@
 //            states), the horizontal path is read back from hscan's volume.
 //
 // Lane mapping: a "lane-row" of 16 lanes (one DPP row) owns one pixel at a time; each lane holds 16
-// consecutive disparities as 8 registers of packed u16 pairs, interleaved as
-//   A_g = [d(4g) | d(4g+2)],  B_g = [d(4g+1) | d(4g+3)]          (g = 0..3)
-// so the d-1 / d+1 neighbours of a register are the sibling register or one v_alignbit away.  Path
-// states are kept normalised (N = L' - min L'), which turns the recursion into
+// consecutive disparities as 8 registers of packed u16 pairs,
+//   R_r = [e = r | e = r + 8]          (r = 0..7, e = disparity index inside the lane)
+// so the d-1 / d+1 neighbours of a whole register are the registers R_(r-1) and R_(r+1); only R_0 and R_7
+// need one v_alignbit each to splice in the neighbouring lane.  Path states are kept normalised
+// (N = L' - min L'), which turns the recursion into
 //   L'(d) = C(d) + min(N(d), P2, P1 + min(N(d-1), N(d+1)))
 // in packed 16-bit arithmetic; the minimum over d is a register tree plus four DPP steps.
+// Three-input minima use v_pk_minimum3_f16: bit patterns below 0x7C00 are non-negative finite halfs (subnormals
+// included, which the default mode keeps) and order exactly like the integers they are, so every packed
+// value here stays below 0x7C00 ("infinite" is 0x6000, P1 < 2048, sums < 4096).
 #include "common.h"
 
 namespace {
@@ -34,7 +38,14 @@ __device__ __forceinline__ u32 pkadd(u32 a, u32 b) { return asu(asv(a) + asv(b))
 __device__ __forceinline__ u32 pksub(u32 a, u32 b) { return asu(asv(a) - asv(b)); }
 __device__ __forceinline__ u32 pkmin(u32 a, u32 b) { return asu(__builtin_elementwise_min(asv(a), asv(b))); }
 
-constexpr u32 INF2 = 0x7F007F00u;   // "infinite" packed pair; INF + P1 cannot wrap (P1 < 8192)
+constexpr u32 INF1 = 0x6000u;       // "infinite": INF + 4095 + P1 stays below 0x7C00 (P1 < 2048)
+constexpr u32 INF2 = INF1 | (INF1 << 16);
+__device__ __forceinline__ u32 pkmin3(u32 a, u32 b, u32 c)
+{
+    u32 r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 #define DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
 #define DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
@@ -85,9 +96,8 @@ __device__ __forceinline__ void make_tail(int lic, int D, u32 (&tail)[NR])
 {
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int g = r >> 1, odd = r & 1;
-        const int dlo = lic * DPL + 4 * g + odd, dhi = dlo + 2;
-        tail[r] = (dlo >= D ? 0x00007F00u : 0u) | (dhi >= D ? 0x7F000000u : 0u);
+        const int dlo = lic * DPL + r, dhi = dlo + 8;
+        tail[r] = (dlo >= D ? INF1 : 0u) | (dhi >= D ? INF1 << 16 : 0u);
     }
 }
 
@@ -103,12 +113,13 @@ __device__ __forceinline__ void load_cost_operands(const Sgm2Args& a, const u8* 
 __device__ __forceinline__ void cost_from_operands(u32 cl, const uint4& rb, u32 (&C)[NR])
 {
     const u32 m = cl * 0x01010101u;
-    const u32 w[4] = {rb.x ^ m, rb.y ^ m, rb.z ^ m, rb.w ^ m};
+    // dword 3 - k holds e = 4k .. 4k+3 as bytes 3,2,1,0
+    const u32 w[4] = {rb.w ^ m, rb.z ^ m, rb.y ^ m, rb.x ^ m};
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const u32 x = w[3 - g];   // dword holding e = 4g .. 4g+3 as bytes 3,2,1,0
-        C[2 * g] = (u32)__popc(x & 0xFF000000u) | ((u32)__popc(x & 0x0000FF00u) << 16);       // [e=4g   | e=4g+2]
-        C[2 * g + 1] = (u32)__popc(x & 0x00FF0000u) | ((u32)__popc(x & 0x000000FFu) << 16);   // [e=4g+1 | e=4g+3]
+    for (int r = 0; r < NR; r++) {
+        const u32 lo = w[r >> 2], hi = w[(r >> 2) + 2];        // e = r and e = r + 8 sit at the same byte of their dwords
+        const u32 mask = 0xFFu << (8 * (3 - (r & 3)));
+        C[r] = (u32)__popc(lo & mask) | ((u32)__popc(hi & mask) << 16);
     }
 }
 
@@ -117,31 +128,28 @@ __device__ __forceinline__ void cost_from_operands(u32 cl, const uint4& rb, u32 
 template <bool TAIL, int LPC = 16>
 __device__ __forceinline__ void sgm_step(u32 (&N)[NR], const u32 (&C)[NR], u32 P1P1, u32 P2P2, const u32 (&tail)[NR], u32 (&L)[NR], int lic = 0)
 {
-    // d-1 of this lane's first disparity lives in the previous lane's last B register (high half),
-    // d+1 of its last disparity in the next lane's first A register (low half)
-    u32 prevB = dpp_keep<DPP_ROW_SHR1>(INF2, N[NR - 1]);
-    u32 nextA = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
+    // d-1 of this lane's first disparity is the previous lane's e = 15 (high half of its R_7),
+    // d+1 of its last disparity the next lane's e = 0 (low half of its R_0)
+    u32 prev7 = dpp_keep<DPP_ROW_SHR1>(INF2, N[NR - 1]);
+    u32 next0 = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
     if (LPC < 16) {   // several pixels share a DPP row: cut the shifts at the pixel's first / last lane
-        prevB = lic == 0 ? INF2 : prevB;
-        nextA = lic == LPC - 1 ? INF2 : nextA;
+        prev7 = lic == 0 ? INF2 : prev7;
+        next0 = lic == LPC - 1 ? INF2 : next0;
     }
-    u32 mn = 0xFFFFFFFFu;
-    u32 O[NR];   // predecessor state (N is overwritten group by group below)
+    u32 O[NR + 2];   // predecessor state framed by its d-1 / d+1 continuations: O[r] = N(d-1) of R_r, O[r+2] = N(d+1)
+    O[0] = __builtin_amdgcn_alignbit(N[NR - 1], prev7, 16);     // [e = -1 | e = 7]
+    O[NR + 1] = __builtin_amdgcn_alignbit(next0, N[0], 16);     // [e = 8  | e = 16]
 #pragma unroll
-    for (int r = 0; r < NR; r++) O[r] = N[r];
+    for (int r = 0; r < NR; r++) O[r + 1] = N[r];
+    u32 mn = 0;
 #pragma unroll
-    for (int g = 0; g < NR / 2; g++) {
-        const u32 A = O[2 * g], B = O[2 * g + 1];
-        const u32 Bm = g == 0 ? prevB : O[2 * g - 1];
-        const u32 An = g == NR / 2 - 1 ? nextA : O[2 * g + 2];
-        const u32 tA = pkmin(__builtin_amdgcn_alignbit(B, Bm, 16), B);       // min(N(d-1), N(d+1)) for A's pair
-        const u32 tB = pkmin(A, __builtin_amdgcn_alignbit(An, A, 16));       // ... for B's pair
-        u32 LA = pkadd(C[2 * g], pkmin(pkmin(A, P2P2), pkadd(tA, P1P1)));
-        u32 LB = pkadd(C[2 * g + 1], pkmin(pkmin(B, P2P2), pkadd(tB, P1P1)));
-        L[2 * g] = LA; L[2 * g + 1] = LB;
-        if (TAIL) { LA |= tail[2 * g]; LB |= tail[2 * g + 1]; }
-        N[2 * g] = LA; N[2 * g + 1] = LB;
-        mn = g == 0 ? pkmin(LA, LB) : pkmin(mn, pkmin(LA, LB));
+    for (int r = 0; r < NR; r++) {
+        const u32 t = pkadd(pkmin(O[r], O[r + 2]), P1P1);
+        u32 Lr = pkadd(C[r], pkmin3(O[r + 1], P2P2, t));
+        L[r] = Lr;
+        if (TAIL) Lr |= tail[r];
+        N[r] = Lr;
+        if (r & 1) mn = r == 1 ? pkmin(N[0], Lr) : pkmin3(mn, N[r - 1], Lr);
     }
     u32 m1 = min(mn & 0xFFFFu, mn >> 16);
     m1 = row_min16<LPC>(m1);
@@ -190,11 +198,11 @@ __device__ __forceinline__ void zero8(u32 (&v)[NR])
     for (int r = 0; r < NR; r++) v[r] = 0;
 }
 
-// path values L' (<= Cmax + P2 <= 255) of one lane as 16 bytes in natural d order, and back
+// path values L' (<= Cmax + P2 <= 255) of one lane as 16 bytes (dword k: e = 2k, 2k+1, 2k+8, 2k+9), and back
 __device__ __forceinline__ uint4 pack_bytes(const u32 (&L)[NR])
 {
     uint4 w;
-    w.x = __builtin_amdgcn_perm(L[1], L[0], 0x06020400u);   // [A.lo, B.lo, A.hi, B.hi] = e 0,1,2,3
+    w.x = __builtin_amdgcn_perm(L[1], L[0], 0x06020400u);   // [R_0.lo, R_1.lo, R_0.hi, R_1.hi] = e 0,1,8,9
     w.y = __builtin_amdgcn_perm(L[3], L[2], 0x06020400u);
     w.z = __builtin_amdgcn_perm(L[5], L[4], 0x06020400u);
     w.w = __builtin_amdgcn_perm(L[7], L[6], 0x06020400u);
@@ -205,8 +213,8 @@ __device__ __forceinline__ void unpack_bytes(const uint4& w, u32 (&L)[NR])
     const u32 v[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        L[2 * g] = __builtin_amdgcn_perm(v[g], v[g], 0x0C020C00u);       // [e 4g   | e 4g+2]
-        L[2 * g + 1] = __builtin_amdgcn_perm(v[g], v[g], 0x0C030C01u);   // [e 4g+1 | e 4g+3]
+        L[2 * g] = __builtin_amdgcn_perm(v[g], v[g], 0x0C020C00u);       // bytes 0, 2 -> R_2g
+        L[2 * g + 1] = __builtin_amdgcn_perm(v[g], v[g], 0x0C030C01u);   // bytes 1, 3 -> R_2g+1
     }
 }
 
@@ -222,9 +230,9 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
     u32 kmin = 0xFFFFFFFFu;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        const u32 idx = (u32)(4 * (q >> 1) + (q & 1)) | ((u32)(4 * (q >> 1) + (q & 1) + 2) << 16);
+        const u32 idx = (u32)q | ((u32)(q + 8) << 16);
         u32 k = asu(asv(Sacc[q]) * (unsigned short)16 + asv(idx));
-        if (TAIL) k |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+        if (TAIL) k |= (tail[q] & 0x0000FFFFu ? 0x0000FFFFu : 0u) | (tail[q] & 0xFFFF0000u ? 0xFFFF0000u : 0u);
         kmin = q == 0 ? k : pkmin(kmin, k);
     }
     const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
@@ -242,7 +250,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
 #pragma unroll
     for (int q = 0; q < NR; q++) {
         u32 v = Sacc[q] | em[q];
-        if (TAIL) v |= (tail[q] & 0x00007F00u ? 0x0000FFFFu : 0u) | (tail[q] & 0x7F000000u ? 0xFFFF0000u : 0u);
+        if (TAIL) v |= (tail[q] & 0x0000FFFFu ? 0x0000FFFFu : 0u) | (tail[q] & 0xFFFF0000u ? 0xFFFF0000u : 0u);
         smin = q == 0 ? v : pkmin(smin, v);
     }
     const int mex = (int)row_min16<LPC>(min(smin & 0xFFFFu, smin >> 16));
@@ -256,7 +264,7 @@ __device__ __forceinline__ void fused_wta(const Sgm2Args& a, const u32 (&Sacc)[N
     auto s_at = [&](int d) -> u32 {
         d = min(max(d, 0), LPC * DPL - 1);
         const int e = d & 15;
-        const int reg = 2 * (e >> 2) + (e & 1), half = (e >> 1) & 1;
+        const int reg = e & 7, half = e >> 3;
         return (srow[(d >> 4) * 8 + reg] >> (16 * half)) & 0xFFFFu;
     };
     const u32 sm = s_at(best - 1), spl = s_at(best + 1);
@@ -273,7 +281,7 @@ __device__ __forceinline__ void init_excl_mask(u32 (*exclMask)[NR])
 {
     for (int i = threadIdx.x; i < 19 * NR; i += blockDim.x) {
         const int t = i / NR, r = i % NR, rel = t - 1;
-        const int elo = 4 * (r >> 1) + (r & 1), ehi = elo + 2;
+        const int elo = r, ehi = r + 8;
         u32 m = 0;
         if (t < 18) {
             if (elo - rel >= -1 && elo - rel <= 1) m |= 0x0000FFFFu;
@@ -523,12 +531,12 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
             if (FUSE) {
                 fused_wta<TAIL>(a, Sacc, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + (size_t)y * W + x);
             } else if (UP && a.naturalOut) {
-                // [A_g.lo|B_g.lo], [A_g.hi|B_g.hi]: pairs of consecutive disparities
+                // [R_2g.lo|R_2g+1.lo] = e 2g, 2g+1;  [R_2g.hi|R_2g+1.hi] = e 2g+8, 2g+9
                 u32 nat[NR];
 #pragma unroll
                 for (int g = 0; g < NR / 2; g++) {
-                    nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
-                    nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                    nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+                    nat[g + 4] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
                 store8(sp, nat);
             } else store8(sp, Sacc);
@@ -793,8 +801,8 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
                 u32 nat[NR];
 #pragma unroll
                 for (int g = 0; g < NR / 2; g++) {
-                    nat[2 * g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
-                    nat[2 * g + 1] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                    nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+                    nat[g + 4] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
                 store8(Sp + (pix * DP + lic * DPL), nat);
             } else if (S4B) store16_stream(Sb + pix * DP + lic * 16, pack_bytes(Sacc));
@@ -954,7 +962,7 @@ size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
 {
-    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && pl.D <= 256 && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 8192 &&
+    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && pl.D <= 256 && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 

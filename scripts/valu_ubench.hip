@@ -10,6 +10,33 @@ __device__ __forceinline__ u32 hsu(h2 v) { return __builtin_bit_cast(u32, v); }
 __device__ __forceinline__ us2 asv(u32 v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ u32 asu(us2 v) { return __builtin_bit_cast(u32, v); }
 
+// three-input minimum of packed u16 pairs below 0x7C00 (bit patterns of non-negative finite halfs order like integers)
+__device__ __forceinline__ u32 pkmin3(u32 a, u32 b, u32 c)
+{
+    u32 r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__global__ void check_min3(u32* bad, u32 seed)
+{
+    u32 s = seed + (blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B9u, n = 0;
+    for (int it = 0; it < 4096; it++) {
+        u32 v[3];
+        for (int j = 0; j < 3; j++) {
+            s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+            u32 lo = s & 0x7FFF, hi = (s >> 16) & 0x7FFF;
+            if (it & 1) { lo &= 0x3FF; hi &= 0xFF; }          // small integers: subnormal halfs
+            if (lo > 0x7C00) lo = 0x7C00;
+            if (hi > 0x7C00) hi = 0x7C00;
+            v[j] = lo | (hi << 16);
+        }
+        const u32 r = pkmin3(v[0], v[1], v[2]);
+        const u32 elo = min(min(v[0] & 0xFFFF, v[1] & 0xFFFF), v[2] & 0xFFFF), ehi = min(min(v[0] >> 16, v[1] >> 16), v[2] >> 16);
+        if (r != (elo | (ehi << 16))) n++;
+    }
+    if (n) atomicAdd(bad, n);
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void k(u32* out, int iters, u32 seed)
 {
@@ -39,6 +66,7 @@ __global__ __launch_bounds__(256) void k(u32* out, int iters, u32 seed)
                 if (OP == 15) a[i] = min(min(a[i], a[(i + 3) & 7]), a[(i + 5) & 7]);                              // v_min3_u32
                 if (OP == 16) a[i] = a[i] + a[(i + 3) & 7] + a[(i + 5) & 7];                                      // v_add3_u32
                 if (OP == 17) a[i] = asu(asv(a[i]) * asv(c) + asv(a[(i + 3) & 7]));                               // v_pk_mad_u16
+                if (OP == 18) a[i] = pkmin3(a[i], a[(i + 3) & 7], a[(i + 5) & 7]);                                // v_pk_minimum3_f16
             }
         }
     }
@@ -85,5 +113,13 @@ int main()
     run<15>("v_min3_u32", 1);
     run<16>("v_add3_u32", 1);
     run<17>("v_pk_mad_u16", 1);
+    run<18>("v_pk_minimum3_f16", 1);
+    {
+        u32* bad; hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+        check_min3<<<256, 256>>>(bad, 12345u);
+        u32 h = 0; hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("v_pk_minimum3_f16 as a u16 min3 (values <= 0x7C00, subnormals included): %u mismatches of %u\n", h, 256u * 256u * 4096u);
+        hipFree(bad);
+    }
     return 0;
 }
