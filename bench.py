@@ -39,8 +39,16 @@ def cpu_baseline(orc, api):
         orc.sgm(L, R, 0, D, P1, P2, 10, 1, 8, 1)
         frames += 1
         dt = time.perf_counter() - t0
-    return {"value": frames * H * W * D / dt / 1e6, "unit": "Mdisp/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} frame(s) of {W}x{H}, D={D}, SGM 8-path + LR + subpixel, {dt:.1f} s of CPU work"}
+    out = {"value": frames * H * W * D / dt / 1e6, "unit": "Mdisp/s", "cores": threads, "kind": "port",
+           "sample": f"{frames} frame(s) of {W}x{H}, D={D}, SGM 8-path + LR + subpixel, {dt:.1f} s of CPU work"}
+    # the same routine on one thread, one frame
+    os.environ["OMP_NUM_THREADS"] = "1"
+    orc.set_threads(1)
+    t0 = time.perf_counter()
+    orc.sgm(L, R, 0, D, P1, P2, 10, 1, 8, 1)
+    out["value_1_thread"] = H * W * D / (time.perf_counter() - t0) / 1e6
+    orc.set_threads(threads)
+    return out
 
 
 def measured_traffic():
@@ -157,6 +165,12 @@ def main():
     torch.cuda.synchronize()
     pair_s = float(np.mean(call_ms)) / 1e3 / B      # device time per pair, whole pipeline
 
+    # what HBM delivers on this device: streaming copy of 2 GiB through the workspace (read + written bytes)
+    copy_gbs = C.c_float(0)
+    half = min(ws_bytes // 2, 2 << 30) // 256 * 256
+    if half >= (64 << 20):
+        _lib.check(lib.mdisp_copy_bandwidth_dev(ctx.handle, ws.data_ptr() + half, ws.data_ptr(), half, 5, C.byref(copy_gbs)))
+
     units_per_pair = W * H * D
     total_units = units_per_pair * args.pairs * args.steps * world
     alg_bytes = ALG_BYTES_PER_UNIT * units_per_pair + ALG_BYTES_PER_PIXEL * W * H
@@ -180,7 +194,9 @@ def main():
             "config": {"workload": f"1920x1080 D={D} census-Hamming cost + SGM {args.paths}-path + WTA/uniqueness + x16 subpixel + LR check",
                        "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_copy": copy_gbs.value or None,
+                         "frac_of_measured": achieved / copy_gbs.value if copy_gbs.value else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "all launches of one batch call, per pair (census, horizontal scan, sheared down sweep, "
                                    "sheared up sweep + WTA, LR/sub-pixel)",
                          "ms_per_pair": pair_s * 1e3, "ms_aggregation_per_pair": float(np.mean(agg_ms)) / B,

@@ -50,6 +50,7 @@ EXPORTS = [
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
+    "mdisp_copy_bandwidth_dev",
 ]
 
 _lib = None
@@ -123,6 +124,7 @@ def load():
     lib.mdisp_asw_gifs_band_stats_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
+    lib.mdisp_copy_bandwidth_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, P(C.c_float)]
     lib.mdisp_synth_pair.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     _lib = lib
     return lib

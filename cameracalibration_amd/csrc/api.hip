@@ -188,6 +188,39 @@ extern "C" int mdisp_last_kernel_ms(mdisp_ctx* c, int which, float* ms)
     return MDISP_OK;
 }
 
+// Streaming copy used to measure what HBM delivers on this device (the denominator next to the nominal peak):
+// 16 bytes per lane and iteration, grid-stride, nontemporal in both directions.
+typedef u32 md_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void md_stream_copy_kernel(const md_u32x4* __restrict__ src, md_u32x4* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+extern "C" int mdisp_copy_bandwidth_dev(mdisp_ctx* c, void* d_dst, const void* d_src, size_t bytes, int reps, float* gb_per_s)
+{
+    MD_REQUIRE(c && d_dst && d_src && gb_per_s, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(bytes >= 16 && bytes % 16 == 0 && reps > 0, MDISP_E_BADARG, "bytes must be a positive multiple of 16, reps > 0");
+    MD_REQUIRE(((uintptr_t)d_dst | (uintptr_t)d_src) % 16 == 0, MDISP_E_BADARG, "buffers must be 16-byte aligned");
+    hipEvent_t e0, e1;
+    MD_HIP(hipEventCreate(&e0));
+    MD_HIP(hipEventCreate(&e1));
+    const size_t n = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    md_stream_copy_kernel<<<blocks, 256, 0, c->stream>>>((const md_u32x4*)d_src, (md_u32x4*)d_dst, n);   // warm-up
+    MD_HIP(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++) md_stream_copy_kernel<<<blocks, 256, 0, c->stream>>>((const md_u32x4*)d_src, (md_u32x4*)d_dst, n);
+    MD_HIP(hipEventRecord(e1, c->stream));
+    MD_HIP(hipGetLastError());
+    MD_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    MD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *gb_per_s = (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+    return MDISP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // helpers
 

@@ -341,6 +341,11 @@ int mdisp_asw_gifs_band_stats_dev(mdisp_ctx*, const uint8_t* d_left, const uint8
  * and sweep kernel of the call), 2: the separate winner-take-all kernel of the per-direction
  * fallback (not recorded when winner-take-all is fused into the upward sweep) */
 int mdisp_last_kernel_ms(mdisp_ctx*, int which, float* ms);
+
+/* Measurement aid, no counterpart in the reference: copies `bytes` (a multiple of 16) from d_src to d_dst `reps`
+ * times with a streaming kernel on the context's stream and reports read + written GB/s (HIP events).  bench.py
+ * quotes it next to the nominal HBM peak. */
+int mdisp_copy_bandwidth_dev(mdisp_ctx*, void* d_dst, const void* d_src, size_t bytes, int reps, float* gb_per_s);
 int mdisp_enable_timing(mdisp_ctx*, int on);
 
 /* ---- synthetic rectified pair generator used by the tests and the benchmark (host) ----

@@ -149,6 +149,9 @@ void orc_stereo_rectify(const double K1[9], const double* D1, const double K2[9]
 void orc_reproject_q(const float* disp, int H, int W, const double Q[16], float* xyz);
 void orc_reproject_triangulate(const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz);
 
+/* number of OpenMP threads the row-parallel loops use from now on (bench.py times one thread beside all cores) */
+void orc_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

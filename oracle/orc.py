@@ -52,6 +52,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads used by the row-parallel loops from now on."""
+    lib().orc_set_threads(int(n))
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

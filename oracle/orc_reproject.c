@@ -64,3 +64,15 @@ void orc_reproject_triangulate(const float* disp, int H, int W, const double K[9
         }
     }
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
