@@ -34,8 +34,11 @@ namespace {
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 asv(u32 v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ u32 asu(us2 v) { return __builtin_bit_cast(u32, v); }
-__device__ __forceinline__ u32 pkadd(u32 a, u32 b) { return asu(asv(a) + asv(b)); }
-__device__ __forceinline__ u32 pksub(u32 a, u32 b) { return asu(asv(a) - asv(b)); }
+// Sums and differences of packed pairs whose low halves neither carry nor borrow (every sum here stays below
+// 0x7C00, every difference is value - minimum): plain 32-bit v_add_u32 / v_sub_u32, which issue in about 2.5
+// cycles per wave64 where the packed 16-bit forms take about 4.4 (scripts/valu_ubench2.hip).
+__device__ __forceinline__ u32 pkadd(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 pksub(u32 a, u32 b) { return a - b; }
 __device__ __forceinline__ u32 pkmin(u32 a, u32 b) { return asu(__builtin_elementwise_min(asv(a), asv(b))); }
 
 constexpr u32 INF1 = 0x6000u;       // "infinite": INF + 4095 + P1 stays below 0x7C00 (P1 < 2048)
@@ -213,7 +216,7 @@ __device__ __forceinline__ void unpack_bytes(const uint4& w, u32 (&L)[NR])
     const u32 v[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        L[2 * g] = __builtin_amdgcn_perm(v[g], v[g], 0x0C020C00u);       // bytes 0, 2 -> R_2g
+        L[2 * g] = v[g] & 0x00FF00FFu;                                   // bytes 0, 2 -> R_2g
         L[2 * g + 1] = __builtin_amdgcn_perm(v[g], v[g], 0x0C030C01u);   // bytes 1, 3 -> R_2g+1
     }
 }
