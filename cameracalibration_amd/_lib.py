@@ -33,6 +33,12 @@ class mdisp_stereosgbm_params(C.Structure):
                                        "uniquenessRatio", "speckleWindowSize", "speckleRange", "mode")]
 
 
+class mdisp_stereobm_params(C.Structure):
+    """cv::StereoBM::create(numDisparities, blockSize) and its setters"""
+    _fields_ = [(n, C.c_int) for n in ("minDisparity", "numDisparities", "blockSize", "preFilterCap", "textureThreshold",
+                                       "uniquenessRatio", "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+
+
 class mdisp_sgbm_params(C.Structure):
     _fields_ = [("minDisparity", C.c_int), ("numDisparities", C.c_int), ("P1", C.c_int), ("P2", C.c_int),
                 ("uniquenessRatio", C.c_int), ("disp12MaxDiff", C.c_int), ("paths", C.c_int), ("subpixel", C.c_int),
@@ -50,7 +56,7 @@ EXPORTS = [
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
-    "mdisp_copy_bandwidth_dev",
+    "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev",
 ]
 
 _lib = None
@@ -124,6 +130,11 @@ def load():
     lib.mdisp_asw_gifs_band_stats_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
+    sbp = P(mdisp_stereobm_params)
+    lib.mdisp_stereobm_compute.argtypes = [vp, img, img, sbp, img]
+    lib.mdisp_stereobm_workspace_bytes.argtypes = [C.c_int, C.c_int, sbp]
+    lib.mdisp_stereobm_workspace_bytes.restype = C.c_size_t
+    lib.mdisp_stereobm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sbp, vp, vp, C.c_size_t]
     lib.mdisp_copy_bandwidth_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, P(C.c_float)]
     lib.mdisp_synth_pair.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     _lib = lib

@@ -11,7 +11,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._lib import MdispError, check, image, load, mdisp_param, mdisp_sgbm_params, mdisp_stereosgbm_params
+from ._lib import MdispError, check, image, load, mdisp_param, mdisp_sgbm_params, mdisp_stereobm_params, mdisp_stereosgbm_params
 
 # CENSUS_ALGORITHM, methods_disp.h:18-27
 BASIC_CENSUS, CIRCLE_CENSUS, ROTATION_INVARIANT_CENSUS, UNIFORM_CENSUS, MULTISCALE_CENSUS, \
@@ -21,8 +21,8 @@ AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
 # GIF_TYPE, gifs.h:4-13
 GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 = range(7)
 COST_VOLUME, COST_CENSUS, COST_ABSDIFF = range(3)
-# StereoMatchingAlgorithms, methods/parametersStereo.h (only the entry built here)
-SGBM = 1
+# StereoMatchingAlgorithms, methods/parametersStereo.h:11-24 (the entries built here)
+BM, SGBM = 0, 1
 
 
 @dataclass
@@ -339,10 +339,57 @@ def getDisparity_SGBM(srcLeft, srcRight, ctx=None):
     return np.rint(d16.astype(np.float64) / 16.0).astype(np.int16)
 
 
+class StereoBM:
+    """cv::StereoBM as the reference drives it (methods/methods.cpp:1205-1213, 1829-1838): create(numDisparities, blockSize),
+    the library's defaults for everything else, setters with its names, compute() -> CV_16S disparity x16."""
+
+    def __init__(self, numDisparities=0, blockSize=21):
+        self.p = mdisp_stereobm_params(0, numDisparities if numDisparities > 0 else 64, blockSize, 31, 10, 15, 0, 0, -1)
+
+    @staticmethod
+    def create(numDisparities=0, blockSize=21):
+        return StereoBM(numDisparities, blockSize)
+
+    def setMinDisparity(self, v): self.p.minDisparity = v
+    def setNumDisparities(self, v): self.p.numDisparities = v
+    def setBlockSize(self, v): self.p.blockSize = v
+    def setPreFilterCap(self, v): self.p.preFilterCap = v
+    def setTextureThreshold(self, v): self.p.textureThreshold = v
+    def setUniquenessRatio(self, v): self.p.uniquenessRatio = v
+    def setSpeckleWindowSize(self, v): self.p.speckleWindowSize = v
+    def setSpeckleRange(self, v): self.p.speckleRange = v
+    def setDisp12MaxDiff(self, v): self.p.disp12MaxDiff = v
+
+    def compute(self, left, right, ctx=None):
+        L, R = _u8_image(left), _u8_image(right)       # three channels: converted with COLOR_BGR2GRAY first
+        out = np.empty(L.shape[:2], dtype=np.int16)
+        check(load().mdisp_stereobm_compute(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), C.byref(self.p), C.byref(image(out))))
+        return out
+
+
+def getDisparity_BM(srcLeft, srcRight, ctx=None):
+    """methods/methods.cpp:1825-1881: StereoBM(144, 35), minDisparity 186, textureThreshold 10, disp12MaxDiff -1, preFilterCap 31,
+    uniquenessRatio 25, speckleRange 32, speckleWindowSize 0 -> CV_16S disparity x16 (colour input goes through BGR2GRAY)."""
+    if srcLeft is None or srcRight is None or srcLeft.size == 0 or srcRight.size == 0:
+        print(" --(!) Error reading images ")
+        return None
+    sbm = StereoBM.create(16 * 9, 35)
+    sbm.setMinDisparity(186)
+    sbm.setTextureThreshold(10)
+    sbm.setDisp12MaxDiff(-1)
+    sbm.setPreFilterCap(31)
+    sbm.setUniquenessRatio(25)
+    sbm.setSpeckleRange(32)
+    sbm.setSpeckleWindowSize(0)
+    return sbm.compute(srcLeft, srcRight, ctx)
+
+
 def stereoMatching(srcLeft, srcRight, algorithmType=SGBM, ctx=None):
-    """methods/methods.cpp:1776-1813 (SGBM entry)."""
+    """methods/methods.cpp:1776-1813: the BM and SGBM entries (the adaptive-weight research variants are not built)."""
+    if algorithmType == BM:
+        return getDisparity_BM(srcLeft, srcRight, ctx)
     if algorithmType != SGBM:
-        raise NotImplementedError("only the SGBM entry of stereoMatching is on the hot path")
+        raise NotImplementedError("only the BM and SGBM entries of stereoMatching are built")
     return getDisparity_SGBM(srcLeft, srcRight, ctx)
 
 

@@ -867,6 +867,51 @@ extern "C" int mdisp_stereosgbm_dev(mdisp_ctx* c, const uint8_t* dL, const uint8
     return md_stereosgbm_run(c->stream, dL, dR, pitch, rows, cols, channels, p, dDisp, ws, nullptr, nullptr);
 }
 
+extern "C" size_t mdisp_stereobm_workspace_bytes(int rows, int cols, const mdisp_stereobm_params* p)
+{
+    if (!p || rows <= 0 || cols <= 0 || md_stereobm_check(rows, cols, p)) return 0;
+    return md_stereobm_bytes(rows, cols, p);
+}
+
+extern "C" int mdisp_stereobm_dev(mdisp_ctx* c, const uint8_t* dL, const uint8_t* dR, int rows, int cols, size_t pitch,
+                                  const mdisp_stereobm_params* p, int16_t* dDisp, void* ws, size_t ws_bytes)
+{
+    MD_REQUIRE(c && dL && dR && dDisp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(rows > 0 && cols > 0 && pitch >= (size_t)cols, MDISP_E_BADARG, "bad geometry");
+    MD_TRY(md_stereobm_check(rows, cols, p));
+    MD_HIP(hipSetDevice(c->device));
+    const size_t need = md_stereobm_bytes(rows, cols, p);
+    if (ws) MD_REQUIRE(ws_bytes >= need, MDISP_E_NOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+    else if (!(ws = mdisp_ws(c, need))) return MDISP_E_NOMEM;
+    return md_stereobm_run(c->stream, dL, dR, pitch, rows, cols, p, dDisp, ws);
+}
+
+extern "C" int mdisp_stereobm_compute(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_stereobm_params* p,
+                                      mdisp_image* out)
+{
+    MD_REQUIRE(c && p, MDISP_E_BADARG, "null argument");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    // the matcher itself takes CV_8UC1; getDisparity_BM converts colour input with COLOR_BGR2GRAY first (methods.cpp:1850-1860)
+    if ((rc = check_out(out, L->rows, L->cols, MDISP_16S, 1, "out"))) return rc;
+    const int H = L->rows, W = L->cols;
+    MD_TRY(md_stereobm_check(H, W, p));
+    MD_HIP(hipSetDevice(c->device));
+    const size_t pitch = md_align((size_t)W, 256), p3 = md_align((size_t)W * 3, 256);
+    const bool colour = L->channels == 3 || R->channels == 3;
+    Carver cv;
+    size_t o_ws = cv.take(md_stereobm_bytes(H, W, p)), o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_d = cv.take((size_t)H * W * 2),
+           o_st = cv.take(colour ? p3 * H : 0);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3)) || (rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
+    MD_TRY(md_stereobm_run(c->stream, base + o_l, base + o_r, pitch, H, W, p, (int16_t*)(base + o_d), base + o_ws));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 2, (size_t)W * 2, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 extern "C" int mdisp_median_blur3_s16(mdisp_ctx* c, const mdisp_image* src, mdisp_image* dst)
 {
     MD_REQUIRE(c, MDISP_E_BADARG, "null context");

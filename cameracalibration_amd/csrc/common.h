@@ -115,6 +115,12 @@ int md_median3_s16(hipStream_t s, const int16_t* src, int H, int W, int16_t* dst
 size_t md_speckle_scratch_bytes(int H, int W);
 int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal, int maxSize, int maxDiff, void* scratch);
 
+// bm.hip: cv::StereoBM
+int md_stereobm_check(int H, int W, const mdisp_stereobm_params* p);
+size_t md_stereobm_bytes(int H, int W, const mdisp_stereobm_params* p);
+int md_stereobm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, const mdisp_stereobm_params* p,
+                    int16_t* dDisp, void* ws);
+
 // legacy.hip: fixed-window matchers of namespace stereomatch_1
 int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, size_t rp, int H, int W, int method, int winSize,
                         int T, int minD, int numD, u8* dOut, size_t op);

@@ -285,6 +285,28 @@ int mdisp_reproject_q(mdisp_ctx*, const mdisp_image* disp, const double Q[16], m
 int mdisp_reproject_triangulate(mdisp_ctx*, const mdisp_image* disp, const double K[9], double baseline,
                                 const mdisp_image* bgr, mdisp_image* xyz);
 
+/* cv::StereoBM as the reference configures it in getDisparity_BM (methods/methods.cpp:1825-1881:
+ * StereoBM::create(144, 35) + setMinDisparity(186), setTextureThreshold(10), setDisp12MaxDiff(-1), setPreFilterCap(31),
+ * setUniquenessRatio(25), setSpeckleRange(32), setSpeckleWindowSize(0)) and at methods/methods.cpp:1205-1213.
+ * The prefilter is PREFILTER_XSOBEL (the library's default; the reference never changes it). */
+typedef struct mdisp_stereobm_params {
+    int minDisparity;       /* >= 0                                                            */
+    int numDisparities;     /* positive multiple of 16, at most 512                            */
+    int blockSize;          /* SADWindowSize: odd, 5..255, smaller than the image              */
+    int preFilterCap;       /* 1..63                                                           */
+    int textureThreshold;   /* >= 0                                                            */
+    int uniquenessRatio;    /* >= 0; 0 disables the test                                       */
+    int speckleWindowSize;  /* 0 disables the speckle filter                                   */
+    int speckleRange;
+    int disp12MaxDiff;      /* < 0 disables the left-right validation                          */
+} mdisp_stereobm_params;
+
+/* cv::StereoBM::compute(left, right, disp): 8-bit single-channel pair in host memory -> out CV_16S HxW, disparity x16,
+ * (minDisparity - 1) * 16 where the matcher rejects a pixel or cannot place its window.  Arguments the library
+ * refuses with an exception return MDISP_E_BADARG. */
+int mdisp_stereobm_compute(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, const mdisp_stereobm_params* p,
+                           mdisp_image* out);
+
 /* ---- device-resident entry points (inputs already in HBM, nothing copied, no sync) ---- */
 
 /* bytes of device workspace mdisp_sgbm_dev needs for one pair */
@@ -295,6 +317,12 @@ size_t mdisp_sgbm_workspace_bytes(int rows, int cols, const mdisp_sgbm_params* p
 size_t mdisp_stereosgbm_workspace_bytes(int rows, int cols, int channels, const mdisp_stereosgbm_params* p);
 int mdisp_stereosgbm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, int channels, size_t pitch,
                          const mdisp_stereosgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
+
+/* cv::StereoBM::compute (see mdisp_stereobm_compute) on device-resident CV_8UC1 images; d_disp: device int16 HxW;
+ * d_workspace: at least mdisp_stereobm_workspace_bytes() of device memory, or NULL to use the context's own. */
+size_t mdisp_stereobm_workspace_bytes(int rows, int cols, const mdisp_stereobm_params* p);
+int mdisp_stereobm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                       const mdisp_stereobm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
 
 /* d_left/d_right: device CV_8UC1 with the given pitch; d_disp: device int16 HxW (pitch = cols*2).
  * d_workspace: at least mdisp_sgbm_workspace_bytes() of device memory, or NULL to use the

@@ -71,9 +71,16 @@ inline void steerFilter(cv::Mat src, cv::Mat& dst) { mdisp::steerFilter(src, dst
 // cv::StereoSGBM::create(...)->compute(...) call sites (methods/methods.cpp:1216-1219, 1291, 1565-1568, 1650, 1893, 1912):
 // `mdisp_cv::StereoSGBM::create(0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, mdisp_cv::StereoSGBM::MODE_SGBM)->compute(l, r, d)`
 namespace mdisp_cv { typedef mdisp::StereoSGBMT<cv::Mat> StereoSGBM; }
+// cv::StereoBM::create(ndisparities, SADWindowSize) + setters + compute (methods/methods.cpp:1205-1213, 1829-1868)
+namespace mdisp_cv { typedef mdisp::StereoBMT<cv::Mat> StereoBM; }
 
 // methods/methods.h:33
 inline void getDisparity_SGBM(cv::Mat srcLeft, cv::Mat srcRight, cv::Mat& disparityMap) { mdisp::getDisparity_SGBM(srcLeft, srcRight, disparityMap); }
+// methods/methods.h:27, 32
+inline void getDisparity_BM(cv::Mat srcLeft, cv::Mat srcRight, cv::Mat& disparityMap) { mdisp::getDisparity_BM(srcLeft, srcRight, disparityMap); }
+using mdisp::StereoMatchingAlgorithms;
+inline void stereoMatching(cv::Mat srcLeft, cv::Mat srcRight, cv::Mat& disparityMap, StereoMatchingAlgorithms algorithmType)
+{ mdisp::stereoMatching(srcLeft, srcRight, disparityMap, algorithmType); }
 
 // methods/methods.h:27, methods/methods.cpp:1670-1766.  Same XML keys, same stereoRectify flags
 // (CALIB_ZERO_DISPARITY, alpha = 0), maps in CV_16SC2 fixed point, remap on the GPU; the 600-pixel

@@ -309,6 +309,72 @@ template <class M> void getDisparity_SGBM(M srcLeft, M srcRight, M& disparityMap
     }
 }
 
+// cv::StereoBM as the reference uses it (methods/methods.cpp:1205-1213, 1829-1838): create(numDisparities, blockSize), the
+// library's defaults for every other parameter, its setter names, compute() -> CV_16S x16.
+template <class M> class StereoBMT {
+public:
+    static StereoBMT create(int numDisparities = 0, int blockSize = 21)
+    {
+        StereoBMT s;
+        const mdisp_stereobm_params p = {0, numDisparities > 0 ? numDisparities : 64, blockSize, 31, 10, 15, 0, 0, -1};
+        s.params = p;
+        return s;
+    }
+    StereoBMT* operator->() { return this; }
+    void setMinDisparity(int v) { params.minDisparity = v; }
+    void setNumDisparities(int v) { params.numDisparities = v; }
+    void setBlockSize(int v) { params.blockSize = v; }
+    void setPreFilterCap(int v) { params.preFilterCap = v; }
+    void setTextureThreshold(int v) { params.textureThreshold = v; }
+    void setUniquenessRatio(int v) { params.uniquenessRatio = v; }
+    void setSpeckleWindowSize(int v) { params.speckleWindowSize = v; }
+    void setSpeckleRange(int v) { params.speckleRange = v; }
+    void setDisp12MaxDiff(int v) { params.disp12MaxDiff = v; }
+    void compute(M left, M right, M& disparity) const
+    {
+        typedef mat_traits<M> T;
+        mdisp_image l = T::view(left), r = T::view(right);
+        T::create(disparity, l.rows, l.cols, MDISP_16S, 1);
+        mdisp_image d = T::view(disparity);
+        detail::check(mdisp_stereobm_compute(Context::forThisThread().handle(), &l, &r, &params, &d));
+    }
+    mdisp_stereobm_params params;
+};
+
+// methods/methods.h:32, methods.cpp:1825-1881: the reference's StereoBM parameter set; colour input is converted to gray first
+template <class M> void getDisparity_BM(M srcLeft, M srcRight, M& disparityMap)
+{
+    typedef mat_traits<M> T;
+    StereoBMT<M> sbm = StereoBMT<M>::create(16 * 9, 35);
+    sbm.setMinDisparity(186);
+    sbm.setTextureThreshold(10);
+    sbm.setDisp12MaxDiff(-1);
+    sbm.setPreFilterCap(31);
+    sbm.setUniquenessRatio(25);
+    sbm.setSpeckleRange(32);
+    sbm.setSpeckleWindowSize(0);
+    if (T::empty(srcLeft) || T::empty(srcRight)) { std::cout << " --(!) Error reading images " << std::endl; return; }
+    sbm.compute(srcLeft, srcRight, disparityMap);
+}
+
+// methods/parametersStereo.h:11-24
+enum StereoMatchingAlgorithms {
+    BM = 0, SGBM = 1, ADAPTIVE_WEIGHT = 2, ADAPTIVE_WEIGHT_8DIRECT = 3, ADAPTIVE_WEIGHT_GEODESIC = 4, ADAPTIVE_WEIGHT_BILATERAL_GRID = 5,
+    ADAPTIVE_WEIGHT_BLO1 = 6, ADAPTIVE_WEIGHT_GUIDED_FILTER = 7, ADAPTIVE_WEIGHT_GUIDED_FILTER_2 = 8, ADAPTIVE_WEIGHT_GUIDED_FILTER_3 = 9,
+    ADAPTIVE_WEIGHT_MEDIAN = 10
+};
+
+// methods/methods.h:27, methods.cpp:1776-1813.  BM and SGBM run on the GPU; the adaptive-weight research variants of
+// namespace stereomatch_1 are not built and leave disparityMap untouched after a message.
+template <class M> void stereoMatching(M srcLeft, M srcRight, M& disparityMap, StereoMatchingAlgorithms algorithmType)
+{
+    switch (algorithmType) {
+    case BM: getDisparity_BM(srcLeft, srcRight, disparityMap); break;
+    case SGBM: getDisparity_SGBM(srcLeft, srcRight, disparityMap); break;
+    default: std::cout << "stereoMatching: algorithm " << (int)algorithmType << " is not built (BM and SGBM are)" << std::endl;
+    }
+}
+
 // PatchMatch::postProcess validity test, methods/patchmatch.cpp:817-828
 template <class M> void lrCheck(M dispL, M dispR, float thresh, M& validL, M& validR)
 {
@@ -372,6 +438,7 @@ template <class M> void reprojectTriangulate(M disparityMap, const double K_new[
 
 typedef StereoMatchParamT<Mat> StereoMatchParam;
 typedef StereoSGBMT<Mat> StereoSGBM;
+typedef StereoBMT<Mat> StereoBM;
 
 // namespace stereomatch_1, methods/method_StereoMatching.h:94-112: the fixed-window matchers with the
 // reference's names, argument order, defaults and error behaviour ("winsize must be odd" + empty image).

@@ -149,6 +149,15 @@ void orc_stereo_rectify(const double K1[9], const double* D1, const double K2[9]
 void orc_reproject_q(const float* disp, int H, int W, const double Q[16], float* xyz);
 void orc_reproject_triangulate(const float* disp, int H, int W, const double K[9], double baseline, const float* bgr, float* xyz);
 
+/* ---- cv::StereoBM (orc_bm.c) ---- */
+typedef struct {
+    int minDisparity, numDisparities, blockSize, preFilterCap, textureThreshold, uniquenessRatio, speckleWindowSize, speckleRange,
+        disp12MaxDiff;
+} orc_bm_params;
+void orc_bm_prefilter_xsobel(const uint8_t* src, int H, int W, int cap, uint8_t* dst);
+/* 8-bit single-channel pair -> CV_16S disparity x16; returns -1 for arguments the library rejects */
+int orc_stereobm(const uint8_t* L, const uint8_t* R, int H, int W, const orc_bm_params* p, int16_t* disp);
+
 /* number of OpenMP threads the row-parallel loops use from now on (bench.py times one thread beside all cores) */
 void orc_set_threads(int n);
 

@@ -33,6 +33,11 @@ class orc_sgbm_bt_params(C.Structure):
 MODE_SGBM, MODE_HH = 0, 1
 
 
+class orc_bm_params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("minDisparity", "numDisparities", "blockSize", "preFilterCap", "textureThreshold",
+                                       "uniquenessRatio", "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+
+
 def build(force=False):
     srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h")) or f == "Makefile"]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
@@ -371,3 +376,24 @@ def legacy_disparity(L, R, method, winSize=7, threshold_T=30, minDisparity=0, nu
     out = np.empty((H, W), np.uint8)
     rc = lib().orc_legacy_disparity(_p(L), _p(R), H, W, method, winSize, threshold_T, minDisparity, numDisparity, _p(out))
     return None if rc else out
+
+
+def bm_prefilter_xsobel(img, cap=31):
+    img = _u8(img)
+    out = np.empty_like(img)
+    lib().orc_bm_prefilter_xsobel(_p(img), img.shape[0], img.shape[1], cap, _p(out))
+    return out
+
+
+def stereobm(L, R, numDisparities=64, blockSize=21, minDisparity=0, preFilterCap=31, textureThreshold=10, uniquenessRatio=15,
+             speckleWindowSize=0, speckleRange=0, disp12MaxDiff=-1):
+    """cv::StereoBM::create(numDisparities, blockSize) + setters -> compute(): CV_16S disparity x16."""
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    p = orc_bm_params(minDisparity, numDisparities, blockSize, preFilterCap, textureThreshold, uniquenessRatio, speckleWindowSize,
+                      speckleRange, disp12MaxDiff)
+    disp = np.empty((H, W), np.int16)
+    rc = lib().orc_stereobm(_p(L), _p(R), H, W, C.byref(p), _p(disp))
+    if rc:
+        raise ValueError("StereoBM: bad parameters")
+    return disp

@@ -66,6 +66,17 @@ int main(int argc, char** argv)
     Mat dLeg = stereomatch_1::computeSSD_BFOpti(L, R, 7, 0, maxD + 1);                                        // method_StereoMatching.h:112
     if (dLeg.empty()) return fail("empty stereomatch_1 output");
     std::fwrite(dLeg.data(), 1, (size_t)H * W, f);
+    // cv::StereoBM the way methods.cpp:1829-1838 drives it (smaller range and window), and the stereoMatching() dispatcher
+    Mat dBm, dDispatch;
+    StereoBM sbm = StereoBM::create(16, 9);
+    sbm->setMinDisparity(2);
+    sbm->setTextureThreshold(10);
+    sbm->setUniquenessRatio(25);
+    sbm->compute(L, R, dBm);
+    stereoMatching(L, R, dDispatch, SGBM);                                                                    // methods.cpp:1776-1813
+    if (dBm.empty() || dDispatch.empty()) return fail("empty StereoBM / stereoMatching output");
+    std::fwrite(dBm.data(), 2, (size_t)H * W, f);
+    std::fwrite(dDispatch.data(), 2, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

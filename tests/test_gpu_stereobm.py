@@ -1,0 +1,77 @@
+"""GPU parity of the cv::StereoBM replacement (x-Sobel prefilter, window SAD, texture / uniqueness tests, sub-pixel fit,
+left-right validation, speckle filter) against the CPU oracle: integer work, bit-exact.  The oracle restates OpenCV's
+published algorithm; nothing in the reference pins it (parity with the real library is unverified), so these tests pin the
+GPU path to the restatement only."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # H, W, planted shift range, numDisparities, blockSize, then setters
+    (60, 200, 24, 32, 9, {}),
+    (61, 180, 20, 16, 5, {"minDisparity": 7}),                                         # odd height: flat last prefilter row
+    (70, 400, 100, 144, 15, {"minDisparity": 20, "uniquenessRatio": 25}),              # five waves of candidates
+    (50, 260, 60, 64, 11, {"uniquenessRatio": 0, "textureThreshold": 0}),
+    (64, 220, 30, 48, 7, {"disp12MaxDiff": 1}),
+    (64, 220, 30, 48, 7, {"disp12MaxDiff": 0, "minDisparity": 3}),
+    (90, 240, 30, 32, 9, {"speckleWindowSize": 40, "speckleRange": 2}),
+    (48, 160, 30, 32, 21, {"textureThreshold": 4000, "preFilterCap": 10}),             # many windows fail the texture test
+    (40, 60, 10, 64, 9, {}),                                                           # narrower than the range: all FILTERED
+    (30, 700, 200, 512, 7, {"uniquenessRatio": 5}),                                    # the largest range that is built
+]
+
+
+def _run(api, orc, L, R, nd, bs, kw):
+    bm = api.StereoBM.create(nd, bs)
+    for k, v in kw.items():
+        getattr(bm, "set" + k[0].upper() + k[1:])(v)
+    got = bm.compute(L, R)
+    exp = orc.stereobm(L, R, nd, bs, **kw)
+    return got, exp
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stereobm_bit_exact(api, orc, case):
+    H, W, D, nd, bs, kw = case
+    L, R, _ = api.synth_pair(0x5EED0001 + 2 * H, H, W, D)
+    got, exp = _run(api, orc, L, R, nd, bs, kw)
+    assert got.dtype == np.int16 and got.shape == (H, W)
+    assert np.array_equal(got, exp)
+    filtered = (kw.get("minDisparity", 0) - 1) * 16
+    if W > nd + kw.get("minDisparity", 0) + bs:
+        assert (got != filtered).any()          # the case exercises the matcher, not only the frame
+
+
+def test_stereobm_on_the_bundled_pair(api, orc):
+    import os
+    from PIL import Image
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    L = np.array(Image.open(os.path.join(g, "bundled_rectifyL_640x360.pgm")))
+    R = np.array(Image.open(os.path.join(g, "bundled_rectifyR_640x360.pgm")))
+    got, exp = _run(api, orc, L, R, 96, 11, {"minDisparity": 4, "uniquenessRatio": 25, "speckleRange": 32})
+    assert np.array_equal(got, exp)
+
+
+def test_getDisparity_BM_parameters_and_colour_input(api, orc):
+    # the reference's own parameter set (144 candidates from 186, 35x35 windows) on a pair wide enough for it; colour
+    # input goes through the BGR -> gray conversion first
+    H, W = 80, 620
+    L, R, _ = api.synth_pair(0x5EED0041, H, W, 64)
+    R = np.roll(R, -200, axis=1)                 # push the planted disparities into [186, 330)
+    got = api.getDisparity_BM(L, R)
+    exp = orc.stereobm(L, R, 144, 35, minDisparity=186, textureThreshold=10, disp12MaxDiff=-1, preFilterCap=31, uniquenessRatio=25,
+                       speckleRange=32, speckleWindowSize=0)
+    assert np.array_equal(got, exp)
+    assert (got > 185 * 16).any()
+    L3 = np.stack([L, L, L], axis=-1)
+    R3 = np.stack([R, R, R], axis=-1)
+    assert np.array_equal(api.stereoMatching(L3, R3, api.BM), exp)      # gray(B=G=R=v) == v
+
+
+def test_stereobm_rejects_what_the_library_rejects(api):
+    from cameracalibration_amd._lib import MdispError
+    img = np.zeros((40, 80), np.uint8)
+    for nd, bs in ((20, 9), (32, 8), (32, 3), (32, 41)):
+        with pytest.raises(MdispError):
+            api.StereoBM.create(nd, bs).compute(img, img)

@@ -346,3 +346,30 @@ def test_legacy_matchers_known_answers(orc):
     d = orc.legacy_disparity(Lc, Rc, orc.LEGACY_AD, 1, 0, 0, 8)
     assert (d[:, 8:] == 0).all()               # |0 - R| is smallest at the first candidate (smallest column)
     assert orc.legacy_disparity(L, R, orc.LEGACY_SAD, 6, 30, 0, 16) is None      # even window
+
+
+def test_stereobm_oracle_known_answers(orc):
+    # prefilter: a constant image has no x-gradient -> `cap` everywhere; a steep ramp saturates at 2*cap inside the frame
+    flat = np.full((6, 9), 77, np.uint8)
+    assert (orc.bm_prefilter_xsobel(flat, 31) == 31).all()
+    ramp = np.tile((np.arange(9) * 20).astype(np.uint8), (6, 1))
+    pf = orc.bm_prefilter_xsobel(ramp, 31)
+    assert (pf[:, 1:-1] == 62).all() and (pf[:, 0] == 31).all() and (pf[:, -1] == 31).all()
+    odd = orc.bm_prefilter_xsobel(np.tile((np.arange(9) * 20).astype(np.uint8), (5, 1)), 31)
+    assert (odd[4] == 31).all() and (odd[:4, 1:-1] == 62).all()          # odd height: the unpaired last row stays flat
+    # a pair that differs by a pure shift: every pixel of the valid rectangle reports that shift; the window sum is 0
+    # there, so the sub-pixel term (p - n) * 256 / (2 max(p, n)) stays within half a pixel
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (40, 160)).astype(np.uint8)
+    R = base[:, 20:140]
+    L = base[:, 20 - 9:140 - 9]                 # L(x) = R(x - 9)
+    d = orc.stereobm(L, R, 16, 7, uniquenessRatio=0, textureThreshold=0)
+    FILTERED = -16
+    inner = d[3:-3, 15 + 3:-3]
+    assert (d[:3] == FILTERED).all() and (d[:, :15 + 3] == FILTERED).all() and (d[:, -3:] == FILTERED).all()
+    assert (inner != FILTERED).all()
+    assert (np.abs(inner - 9 * 16) <= 8).all()
+    # arguments the library refuses
+    for nd, bs in ((20, 7), (16, 6), (16, 3)):
+        with pytest.raises(ValueError):
+            orc.stereobm(L, R, nd, bs)
