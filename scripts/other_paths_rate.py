@@ -89,3 +89,22 @@ for (H, W, args) in ((480, 640, (0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, 0)), (
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print(f"StereoSGBM (BT, block 7, mode {args[-1]}) {W}x{H} D={args[1]} device-resident: {dt*1e3:.2f} ms  {H*W*args[1]/dt/1e6:.0f} Mdisp/s")
+
+# cv::StereoBM replacement, device-resident: the reference's getDisparity_BM parameters (144 candidates from 186, 35x35
+# windows) at its 1280x720 working size, and a VGA / 64 / 21x21 case
+for (H, W, nd, bs, mind) in ((720, 1280, 144, 35, 186), (480, 640, 64, 21, 0), (1080, 1920, 256, 21, 0)):
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, nd)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    out = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    p = _lib.mdisp_stereobm_params(mind, nd, bs, 31, 10, 25, 0, 32, -1)
+    nb = lib.mdisp_stereobm_workspace_bytes(H, W, C.byref(p))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    def run():
+        _lib.check(lib.mdisp_stereobm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), H, W, W, C.byref(p), out.data_ptr(), ws.data_ptr(), nb))
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    print(f"StereoBM (block {bs}, minD {mind}) {W}x{H} D={nd} device-resident: {dt*1e3:.2f} ms  {H*W*nd/dt/1e6:.0f} Mdisp/s")

@@ -4,8 +4,11 @@ others) of bench.py into VALU instructions per stereo pair and the issue-bound t
 
 usage: sq_summary.py <counter_collection.csv> <pairs per launch> <out.json>
 
-Counts are per launch (SQ_WAVES equals the number of waves launched).  One wave64 VALU instruction holds its SIMD
-for 4 cycles (measured, scripts/valu_ubench.hip); the chip has 256 CUs x 4 SIMDs at 2.4 GHz."""
+Counts are per launch (SQ_WAVES equals the number of waves launched).  One wave64 VALU instruction is priced at
+4 cycles of its SIMD (measured: about 4.2 for packed, three-operand, min/max, shift, permute and bit-count
+instructions, about 2.5 for plain 32-bit add / sub / and / or / xor, scripts/valu_ubench2.hip; the counter does not
+tell the two kinds apart, so the figure is an estimate of the issue time, not a hard floor); the chip has 256 CUs x
+4 SIMDs at 2.4 GHz."""
 import collections
 import csv
 import json
