@@ -56,7 +56,7 @@ EXPORTS = [
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
-    "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev",
+    "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
 ]
 
 _lib = None
@@ -135,6 +135,7 @@ def load():
     lib.mdisp_stereobm_workspace_bytes.argtypes = [C.c_int, C.c_int, sbp]
     lib.mdisp_stereobm_workspace_bytes.restype = C.c_size_t
     lib.mdisp_stereobm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sbp, vp, vp, C.c_size_t]
+    lib.mdisp_fgs_filter.argtypes = [vp, img, img, C.c_double, C.c_double, C.c_double, C.c_int, img]
     lib.mdisp_copy_bandwidth_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, P(C.c_float)]
     lib.mdisp_synth_pair.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     _lib = lib

@@ -393,6 +393,23 @@ def stereoMatching(srcLeft, srcRight, algorithmType=SGBM, ctx=None):
     return getDisparity_SGBM(srcLeft, srcRight, ctx)
 
 
+def fastGlobalSmootherFilter(guide, src, lambda_=8000.0, sigma_color=0.5, lambda_attenuation=0.25, num_iter=3, ctx=None):
+    """ximgproc::fastGlobalSmootherFilter: guide uint8 HxW or HxWx3, src float32 or int16 HxW -> same type as src."""
+    g = _u8_image(guide)
+    s = np.ascontiguousarray(src) if np.asarray(src).dtype == np.int16 else np.ascontiguousarray(src, dtype=np.float32)
+    out = np.empty_like(s)
+    check(load().mdisp_fgs_filter(_ctx(ctx), C.byref(image(g)), C.byref(image(s)), lambda_, sigma_color, lambda_attenuation, num_iter,
+                                  C.byref(image(out))))
+    return out
+
+
+def postProcess_(param, dispL, dispR, ctx=None):
+    """disp_method/methods_disp.cpp:1299-1313: createDisparityWLSFilterGeneric(false), lambda 8000, sigmaColor 0.5, whole-frame
+    ROI, applied to the left map with the left view and to the right map with the right view -> (filteredDispL, filteredDispR)."""
+    return (fastGlobalSmootherFilter(param.imgLeft, dispL, 8000.0, 0.5, ctx=ctx),
+            fastGlobalSmootherFilter(param.imgRight, dispR, 8000.0, 0.5, ctx=ctx))
+
+
 def lr_check(dispL, dispR, thresh=1.0, ctx=None):
     """PatchMatch::postProcess validity masks, methods/patchmatch.cpp:817-828."""
     a = np.ascontiguousarray(dispL, dtype=np.float32)

@@ -912,6 +912,41 @@ extern "C" int mdisp_stereobm_compute(mdisp_ctx* c, const mdisp_image* L, const 
     return MDISP_OK;
 }
 
+extern "C" int mdisp_fgs_filter(mdisp_ctx* c, const mdisp_image* guide, const mdisp_image* src, double lambda, double sigma_color,
+                                double lambda_attenuation, int num_iter, mdisp_image* dst)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(guide, "guide")) || (rc = check_image(src, "src"))) return rc;
+    MD_REQUIRE(guide->depth == MDISP_8U && (guide->channels == 1 || guide->channels == 3), MDISP_E_BADARG, "guide must be CV_8UC1 or CV_8UC3");
+    MD_REQUIRE((src->depth == MDISP_32F || src->depth == MDISP_16S) && src->channels == 1, MDISP_E_UNSUPPORTED,
+               "the filter is built for CV_32FC1 and CV_16SC1 maps");
+    MD_REQUIRE(src->rows == guide->rows && src->cols == guide->cols, MDISP_E_BADARG, "guide / src size mismatch");
+    if ((rc = check_out(dst, src->rows, src->cols, src->depth, 1, "dst"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = src->rows, W = src->cols, cn = guide->channels;
+    const size_t gp = md_align((size_t)W * cn + cn, 256);
+    Carver cv;
+    size_t o_ws = cv.take(md_fgs_bytes(H, W)), o_g = cv.take(gp * (H + 1)), o_u = cv.take((size_t)H * W * 4), o_s = cv.take((size_t)H * W * 2);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base + o_g, gp, guide->data, guide->step_bytes, (size_t)W * cn, H));
+    float* u = (float*)(base + o_u);
+    if (src->depth == MDISP_32F) MD_TRY(md_h2d_2d(c, u, (size_t)W * 4, src->data, src->step_bytes, (size_t)W * 4, H));
+    else {
+        MD_TRY(md_h2d_2d(c, base + o_s, (size_t)W * 2, src->data, src->step_bytes, (size_t)W * 2, H));
+        MD_TRY(md_fgs_convert(c->stream, (const int16_t*)(base + o_s), u, (size_t)H * W));
+    }
+    MD_TRY(md_fgs_filter(c->stream, base + o_g, gp, H, W, cn, u, lambda, sigma_color, lambda_attenuation, num_iter, base + o_ws));
+    if (src->depth == MDISP_32F) MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, u, (size_t)W * 4, (size_t)W * 4, H));
+    else {
+        MD_TRY(md_fgs_convert_back(c->stream, u, (int16_t*)(base + o_s), (size_t)H * W));
+        MD_TRY(md_d2h_2d(c, dst->data, dst->step_bytes, base + o_s, (size_t)W * 2, (size_t)W * 2, H));
+    }
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
 extern "C" int mdisp_median_blur3_s16(mdisp_ctx* c, const mdisp_image* src, mdisp_image* dst)
 {
     MD_REQUIRE(c, MDISP_E_BADARG, "null context");

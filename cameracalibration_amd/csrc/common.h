@@ -121,6 +121,13 @@ size_t md_stereobm_bytes(int H, int W, const mdisp_stereobm_params* p);
 int md_stereobm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, const mdisp_stereobm_params* p,
                     int16_t* dDisp, void* ws);
 
+// fgs.hip: fast global smoother (the WLS post-filter of postProcess_)
+size_t md_fgs_bytes(int H, int W);
+int md_fgs_filter(hipStream_t s, const u8* dGuide, size_t gpitch, int H, int W, int cn, float* dU, double lambda, double sigmaColor,
+                  double attenuation, int iters, void* ws);
+int md_fgs_convert(hipStream_t s, const int16_t* src, float* dst, size_t n);
+int md_fgs_convert_back(hipStream_t s, const float* src, int16_t* dst, size_t n);
+
 // legacy.hip: fixed-window matchers of namespace stereomatch_1
 int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, size_t rp, int H, int W, int method, int winSize,
                         int T, int minD, int numD, u8* dOut, size_t op);

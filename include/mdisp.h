@@ -307,6 +307,14 @@ typedef struct mdisp_stereobm_params {
 int mdisp_stereobm_compute(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, const mdisp_stereobm_params* p,
                            mdisp_image* out);
 
+/* ximgproc::fastGlobalSmootherFilter(guide, src, dst, lambda, sigma_color, lambda_attenuation, num_iter) — what
+ * postProcess_ (disp_method/methods_disp.cpp:1299-1313) runs on both disparity maps through
+ * createDisparityWLSFilterGeneric(false)->filter(disp, view, out, Mat(), whole-frame ROI) with lambda 8000, sigma 0.5
+ * (attenuation 0.25, 3 iterations: the library's defaults).  guide: CV_8UC1 or CV_8UC3; src: CV_32FC1 or CV_16SC1 of the
+ * same size; dst: same type as src.  Float arithmetic in the library's elimination order; tolerance 1e-3 relative. */
+int mdisp_fgs_filter(mdisp_ctx*, const mdisp_image* guide, const mdisp_image* src, double lambda, double sigma_color,
+                     double lambda_attenuation, int num_iter, mdisp_image* dst);
+
 /* ---- device-resident entry points (inputs already in HBM, nothing copied, no sync) ---- */
 
 /* bytes of device workspace mdisp_sgbm_dev needs for one pair */

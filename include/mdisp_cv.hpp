@@ -51,6 +51,9 @@ inline void countHummingDist(cv::Mat src1, cv::Mat src2, cv::Mat& dst) { mdisp::
 inline cv::Mat censusStereo(StereoMatchParam param, CENSUS_ALGORITHM method) { return mdisp::censusStereo(param, method); }
 inline cv::Mat asw_gifs(StereoMatchParam param, double eps, GIF_TYPE gifType = GIF, int r2 = 5, double namda = 0.1, double h = 0.5)
 { return mdisp::asw_gifs(param, eps, gifType, r2, namda, h); }
+// methods_disp.h:69
+inline void postProcess_(StereoMatchParam param, cv::Mat dispL, cv::Mat dispR, cv::Mat& filteredDispL, cv::Mat& filteredDispR)
+{ mdisp::postProcess_(param, dispL, dispR, filteredDispL, filteredDispR); }
 
 // disp_method/gifs.h:17, 21, 27, 33; steerFilter.h:39
 inline cv::Mat getGuidedFilter(cv::Mat guidedImg, cv::Mat inputP, int r, double eps) { return mdisp::getGuidedFilter(guidedImg, inputP, r, eps); }

@@ -157,6 +157,25 @@ template <class M> M asw_gifs(StereoMatchParamT<M> param, double eps, GIF_TYPE g
     });
 }
 
+// ximgproc::fastGlobalSmootherFilter(guide, src, dst, lambda, sigma_color, lambda_attenuation, num_iter); dst gets src's type
+template <class M> void fastGlobalSmootherFilter(M guide, M src, M& dst, double lambda, double sigma_color, double lambda_attenuation = 0.25,
+                                                 int num_iter = 3)
+{
+    typedef mat_traits<M> T;
+    mdisp_image g = T::view(guide), s = T::view(src);
+    T::create(dst, s.rows, s.cols, s.depth, 1);
+    mdisp_image d = T::view(dst);
+    detail::check(mdisp_fgs_filter(Context::forThisThread().handle(), &g, &s, lambda, sigma_color, lambda_attenuation, num_iter, &d));
+}
+
+// postProcess_ (methods_disp.h:69, methods_disp.cpp:1299-1313): createDisparityWLSFilterGeneric(false) with lambda 8000 and
+// sigmaColor 0.5 over the whole frame = the fast global smoother guided by the left / right view
+template <class M> void postProcess_(StereoMatchParamT<M> param, M dispL, M dispR, M& filteredDispL, M& filteredDispR)
+{
+    fastGlobalSmootherFilter(param.imgLeft, dispL, filteredDispL, 8000.0, 0.5);
+    fastGlobalSmootherFilter(param.imgRight, dispR, filteredDispR, 8000.0, 0.5);
+}
+
 // countCensusImg* (methods_disp.h:46-58): dst is allocated here
 template <class M> void countCensusImg(M src, M& dst, CENSUS_ALGORITHM method = BASIC_CENSUS, int arg = 0)
 {

@@ -158,6 +158,13 @@ void orc_bm_prefilter_xsobel(const uint8_t* src, int H, int W, int cap, uint8_t*
 /* 8-bit single-channel pair -> CV_16S disparity x16; returns -1 for arguments the library rejects */
 int orc_stereobm(const uint8_t* L, const uint8_t* R, int H, int W, const orc_bm_params* p, int16_t* disp);
 
+/* ---- fast global smoother / disparity WLS post-filter (orc_fgs.c) ---- */
+void orc_fgs_weights_lut(double sigmaColor, float* lut);
+void orc_fgs_filter_f32(const uint8_t* guide, int H, int W, int cn, const float* src, double lambda, double sigmaColor,
+                        double attenuation, int iters, float* dst);
+void orc_fgs_filter_s16(const uint8_t* guide, int H, int W, int cn, const int16_t* src, double lambda, double sigmaColor,
+                        double attenuation, int iters, int16_t* dst);
+
 /* number of OpenMP threads the row-parallel loops use from now on (bench.py times one thread beside all cores) */
 void orc_set_threads(int n);
 

@@ -397,3 +397,25 @@ def stereobm(L, R, numDisparities=64, blockSize=21, minDisparity=0, preFilterCap
     if rc:
         raise ValueError("StereoBM: bad parameters")
     return disp
+
+
+def fgs_filter(guide, src, lambda_=8000.0, sigma_color=0.5, attenuation=0.25, iters=3):
+    """ximgproc::fastGlobalSmootherFilter(guide, src, dst, lambda, sigma_color, lambda_attenuation, num_iter); src float32 or
+    int16 HxW, dst of the same type."""
+    g = _u8(guide)
+    H, W = g.shape[:2]
+    cn = 1 if g.ndim == 2 else g.shape[2]
+    if src.dtype == np.int16:
+        s = np.ascontiguousarray(src)
+        out = np.empty_like(s)
+        lib().orc_fgs_filter_s16(_p(g), H, W, cn, _p(s), C.c_double(lambda_), C.c_double(sigma_color), C.c_double(attenuation), iters, _p(out))
+        return out
+    s = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.empty_like(s)
+    lib().orc_fgs_filter_f32(_p(g), H, W, cn, _p(s), C.c_double(lambda_), C.c_double(sigma_color), C.c_double(attenuation), iters, _p(out))
+    return out
+
+
+def postProcess_(imgLeft, imgRight, dispL, dispR):
+    """methods_disp.cpp:1299-1313: both maps through the generic WLS filter without confidence (lambda 8000, sigma 0.5)."""
+    return fgs_filter(imgLeft, dispL), fgs_filter(imgRight, dispR)

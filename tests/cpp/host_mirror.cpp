@@ -77,6 +77,12 @@ int main(int argc, char** argv)
     if (dBm.empty() || dDispatch.empty()) return fail("empty StereoBM / stereoMatching output");
     std::fwrite(dBm.data(), 2, (size_t)H * W, f);
     std::fwrite(dDispatch.data(), 2, (size_t)H * W, f);
+    // the post-filter main() runs on the two maps (cameraCalibration.cpp:208); here the left map serves as both
+    Mat fL, fR;
+    postProcess_(p, dOurs, dOurs, fL, fR);
+    if (fL.empty() || fR.empty()) return fail("empty postProcess_ output");
+    std::fwrite(fL.data(), 4, (size_t)H * W, f);
+    std::fwrite(fR.data(), 4, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

@@ -32,7 +32,7 @@ def test_cv_adapter_names_every_boundary_function():
     for name in ("computeSAD_inteOpti", "computeSAD_BFOpti", "censusStereo", "asw_gifs", "countCensusImg", "countHummingDist",
                  "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "getGuidedFilter_ours_gif", "getGuidedFilter_ours_gif2",
                  "getGuidedFilter_ours_gif3", "steerFilter",
-                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "StereoMatchParam"):
+                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam"):
         assert name in text
 
 
@@ -56,7 +56,11 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     dG = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
     dLeg = buf[o:o + n].reshape(H, W); o += n
     dBm = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
-    dDispatch = buf[o:o + 2 * n].view(np.int16).reshape(H, W)
+    dDispatch = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
+    fL = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    fR = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
+    eL, eR = orc.postProcess_(L, R, dO, dO)
+    assert np.abs(fL - eL).max() <= 1e-3 * max(1.0, float(np.abs(eL).max())) and np.abs(fR - eR).max() <= 1e-3 * max(1.0, float(np.abs(eR).max()))
     assert np.array_equal(dBm, orc.stereobm(L, R, 16, 9, minDisparity=2, textureThreshold=10, uniquenessRatio=25))
     assert np.array_equal(dDispatch, dG)
     assert np.array_equal(dLeg, orc.legacy_disparity(L, R, orc.LEGACY_SSD_BF, 7, 30, 0, maxD + 1))

@@ -373,3 +373,42 @@ def test_stereobm_oracle_known_answers(orc):
     for nd, bs in ((20, 7), (16, 6), (16, 3)):
         with pytest.raises(ValueError):
             orc.stereobm(L, R, nd, bs)
+
+
+def test_fgs_oracle_known_answers(orc):
+    from scipy.linalg import solve_banded
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 256, (24, 37), dtype=np.uint8)
+    f = (rng.random((24, 37)) * 90).astype(np.float32)
+    # lambda = 0: the system is the identity
+    assert np.array_equal(orc.fgs_filter(g, f, 0.0, 0.5), f)
+    # a constant map is a fixed point, and every solve preserves the sum (the smoothness term has zero row sums)
+    c = orc.fgs_filter(g, np.full(g.shape, 7.0, np.float32), 8000.0, 5.0)
+    assert np.abs(c - 7.0).max() < 1e-2
+    o = orc.fgs_filter(g, f, 8000.0, 5.0)
+    assert abs(float(o.astype(np.float64).sum()) - float(f.astype(np.float64).sum())) < 1e-3 * f.size
+    assert o.std() < f.std()
+    # a single row, one iteration: the tridiagonal system solved independently in float64
+    row = rng.integers(0, 256, (1, 50), dtype=np.uint8)
+    fr = (rng.random((1, 50)) * 40).astype(np.float32)
+    lam, sig = 30.0, 20.0
+    w = np.exp(-np.abs(np.diff(row[0].astype(np.float64))) / sig)           # weight between x and x+1
+    n = row.shape[1]
+    ab = np.zeros((3, n))
+    ab[0, 1:] = -lam * w
+    ab[2, :-1] = -lam * w
+    ab[1] = 1.0
+    ab[1, :-1] += lam * w
+    ab[1, 1:] += lam * w
+    exp = solve_banded((1, 1), ab, fr[0].astype(np.float64))
+    got = orc.fgs_filter(row, fr, lam, sig, 0.25, 1)
+    assert np.abs(got[0] - exp).max() < 1e-3
+    # three channels: the colour distance is summed over the channels
+    g3 = np.stack([g, g, g], axis=-1)
+    a = orc.fgs_filter(g3, f, 100.0, 30.0)
+    b = orc.fgs_filter(g, f, 100.0, 30.0 / np.sqrt(3.0))
+    assert np.abs(a - b).max() < 1e-2
+    # int16 maps come back rounded
+    d16 = (f * 16).astype(np.int16)
+    o16 = orc.fgs_filter(g, d16, 8000.0, 5.0)
+    assert o16.dtype == np.int16 and np.abs(o16 - np.rint(orc.fgs_filter(g, d16.astype(np.float32), 8000.0, 5.0))).max() == 0
