@@ -86,6 +86,7 @@ struct Sgm2Args {
     u32 P1P1, P2P2;
     int tail;                             // 1 when D < 256: disparities >= D are masked off
     int naturalOut;                       // last sweep: store the full sum in natural d order (volume export)
+    int byteSum;                          // the two byte volumes a sweep adds first (8 paths: horizontal + four-path sum; 5 paths: both horizontals) sum to a byte
     int five;                             // 5-path mode (both horizontals + the three downward paths): the down sweep is the last one
     u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
     uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
@@ -762,16 +763,21 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         u32 C[NR], L[NR], Sacc[NR];
         if (active) {
             cost_from_operands(cl, rb, C);
-            unpack_bytes(hb, Sacc);
-            if (five) {
-                unpack_bytes(hb2, Snext);
+            // byte volumes whose sum still fits a byte are added as bytes (four per plain 32-bit add) and unpacked once
+            if (five && a.byteSum) unpack_bytes(make_uint4(hb.x + hb2.x, hb.y + hb2.y, hb.z + hb2.z, hb.w + hb2.w), Sacc);
+            else if (UP && S4B && a.byteSum) unpack_bytes(make_uint4(hb.x + sb.x, hb.y + sb.y, hb.z + sb.z, hb.w + sb.w), Sacc);
+            else {
+                unpack_bytes(hb, Sacc);
+                if (five) {
+                    unpack_bytes(hb2, Snext);
 #pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
-            }
-            if (UP) {
-                if (S4B) unpack_bytes(sb, Snext);
+                    for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+                }
+                if (UP) {
+                    if (S4B) unpack_bytes(sb, Snext);
 #pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+                    for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], Snext[q]);
+                }
             }
         }
         if (i + 1 < nrows) fetch_row(i + 1);
@@ -1026,6 +1032,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.tail = pl.D < l.slots;
     a.naturalOut = naturalOut;
     a.five = pl.npaths == 5;
+    a.byteSum = (pl.npaths == 5 ? 2 : 5) * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
     a.rec = (uint2*)(hbase + 2 * l.oneH * batch);
     a.strideRec = l.oneRec / sizeof(uint2);
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;

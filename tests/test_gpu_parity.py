@@ -156,6 +156,9 @@ SGM_CASES = [
     (90, 200, 1, 65, 8, 32, 10, 1, 8, 1),       # just above the four-lane limit: eight lanes, masked tail
     (100, 330, 0, 96, 6, 60, 10, 2, 8, 1),      # eight lanes per pixel, 16-bit four-path sums
     (80, 150, 0, 40, 8, 32, 10, 1, 5, 1),       # four lanes per pixel, five paths
+    (50, 120, 0, 64, 8, 200, 10, 1, 5, 1),      # five paths, byte path values whose pairwise sums exceed a byte
+    (50, 120, 0, 64, 8, 44, 10, 1, 8, 1),       # eight paths: byte four-path sums, but horizontal + sum exceeds a byte
+    (50, 120, 0, 64, 8, 43, 10, 1, 8, 1),       # ... and the largest P2 for which it does not
 ]
 
 
