@@ -108,3 +108,11 @@ for (H, W, nd, bs, mind) in ((720, 1280, 144, 35, 186), (480, 640, 64, 21, 0), (
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print(f"StereoBM (block {bs}, minD {mind}) {W}x{H} D={nd} device-resident: {dt*1e3:.2f} ms  {H*W*nd/dt/1e6:.0f} Mdisp/s")
+
+# postProcess_: the WLS post-filter (fast global smoother) on one float map at main()'s working size, host API
+H, W = 720, 1280
+rng = np.random.default_rng(1)
+guide = api.synth_pair(0x5EED0001, H, W, 64)[0]
+dmap = (rng.random((H, W)) * 64).astype(np.float32)
+dt, _ = host_rate(lambda: api.fastGlobalSmootherFilter(guide, dmap, 8000.0, 0.5), H, W, 1, n=5)
+print(f"fastGlobalSmootherFilter (lambda 8000, sigma 0.5, 3 iterations) {W}x{H} host API: {dt*1e3:.2f} ms")
