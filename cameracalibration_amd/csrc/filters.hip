@@ -698,19 +698,25 @@ __global__ __launch_bounds__(256) void bilateral_ab_kernel(BilArgs a)
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // pixels (tx, ty) and (tx, ty + 8) of the tile
     const int c0 = (ty + R) * TW + tx + R, c1 = c0 + 8 * TW;
-    const float2 v0 = biltile[c0], v1 = biltile[c1];
-    float sa0 = 0, wa0 = 0, sb0 = 0, wb0 = 0, sa1 = 0, wa1 = 0, sb1 = 0, wb1 = 0;
+    // the a and b planes of a pixel travel as one packed pair: every step below is a packed fp32 instruction
+    // (v_pk_add / v_pk_mul; products and sums stay separate roundings, as in the library's scalar loop)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2* tile2 = reinterpret_cast<const f2*>(biltile);
+    const f2 v0 = tile2[c0], v1 = tile2[c1];
+    f2 s0 = {0.0f, 0.0f}, w0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f}, w1 = {0.0f, 0.0f};
     const float K = a.colorK;
     for (int t = 0; t < a.ntaps; t++) {
         const int2 tp = a.taps[t];
         const float ws = __int_as_float(tp.y);
-        const float2 p = biltile[c0 + tp.x], q = biltile[c1 + tp.x];
-        float d, w;
-        d = p.x - v0.x; w = ws * __builtin_amdgcn_exp2f(d * d * K); sa0 += __fmul_rn(p.x, w); wa0 += w;
-        d = p.y - v0.y; w = ws * __builtin_amdgcn_exp2f(d * d * K); sb0 += __fmul_rn(p.y, w); wb0 += w;
-        d = q.x - v1.x; w = ws * __builtin_amdgcn_exp2f(d * d * K); sa1 += __fmul_rn(q.x, w); wa1 += w;
-        d = q.y - v1.y; w = ws * __builtin_amdgcn_exp2f(d * d * K); sb1 += __fmul_rn(q.y, w); wb1 += w;
+        const f2 p = tile2[c0 + tp.x], q = tile2[c1 + tp.x];
+        f2 d = p - v0, e = q - v1;
+        d = d * d * K; e = e * e * K;
+        f2 w = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)}, u = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+        w = w * ws; u = u * ws;
+        s0 += p * w; w0 += w;
+        s1 += q * u; w1 += u;
     }
+    const float sa0 = s0.x, sb0 = s0.y, wa0 = w0.x, wb0 = w0.y, sa1 = s1.x, sb1 = s1.y, wa1 = w1.x, wb1 = w1.y;
     const int x = x0 + tx;
     if (x >= a.W) return;
 #pragma unroll
