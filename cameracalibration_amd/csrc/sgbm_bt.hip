@@ -88,6 +88,62 @@ __global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restric
     out[((size_t)y * g.W1 + x1) * g.D + k] = (int16_t)s;
 }
 
+// Pixel cost and horizontal window sum in one pass: a workgroup holds the plane rows of image row y in LDS, lane k
+// marches along the computed columns with a running sum (entering column - leaving column, both with the window
+// clamped to the computed columns), so the pixel costs never reach memory.  Same values as bt_cost_kernel followed by
+// bt_window_kernel<false>.
+#define BT_SEG 128     // columns per marching segment of bt_cost_hsum_kernel
+#define BT_VBAND 120   // rows per marching band of bt_vsum_kernel
+__global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
+                                                           int16_t* __restrict__ out)
+{
+    extern __shared__ u8 planeRows[];                    // [2 * np][W]: left planes, then right planes
+    const int np = 2 * g.cn, W = g.W, y = blockIdx.y;
+    for (int i = threadIdx.x; i < np * W; i += 256) {
+        const int c = i / W, x = i - c * W;
+        planeRows[i] = p1[(size_t)c * g.N + (size_t)y * W + x];
+        planeRows[np * W + i] = p2[(size_t)c * g.N + (size_t)y * W + x];
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= g.D) return;
+    const int h = g.bs / 2, W1 = g.W1;
+    auto pix = [&](int x1) -> int {
+        const int x = x1 + g.minX1, x2 = x - (g.minD + k);
+        int cost = 0;
+        for (int c = 0; c < np; c++) cost += bt_one(planeRows + c * W, planeRows + (np + c) * W, W, x, x2) >> (c < g.cn ? 0 : 2);
+        return cost;
+    };
+    // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window
+    const int xa = blockIdx.z * BT_SEG, xb = min(xa + BT_SEG, W1);
+    int s = 0;
+    for (int i = -h; i <= h; i++) s += pix(min(max(xa + i, 0), W1 - 1));
+    int16_t* o = out + (size_t)y * W1 * g.D + k;
+    o[(size_t)xa * g.D] = (int16_t)s;
+    for (int x1 = xa + 1; x1 < xb; x1++) {
+        s += pix(min(x1 + h, W1 - 1)) - pix(max(x1 - h - 1, 0));
+        o[(size_t)x1 * g.D] = (int16_t)s;
+    }
+}
+
+// Vertical window sum as a running sum down the image (window clamped to the image rows); the first computed
+// column keeps the block cost of row 0 in every row.  Same values as bt_window_kernel<true>.
+__global__ __launch_bounds__(256) void bt_vsum_kernel(const int16_t* __restrict__ in, BtGeom g, int16_t* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, rowN = (size_t)g.W1 * g.D;
+    if (e >= rowN) return;
+    const int h = g.bs / 2, H = g.H;
+    const bool frozen = e < (size_t)g.D;                 // x1 == 0: row 0's sum everywhere
+    const int ya = blockIdx.y * BT_VBAND, yb = min(ya + BT_VBAND, H), yc = frozen ? 0 : ya;
+    int s = 0;
+    for (int i = -h; i <= h; i++) s += in[(size_t)min(max(yc + i, 0), H - 1) * rowN + e];
+    out[(size_t)ya * rowN + e] = (int16_t)s;
+    for (int y = ya + 1; y < yb; y++) {
+        if (!frozen) s += (int)in[(size_t)min(y + h, H - 1) * rowN + e] - (int)in[(size_t)max(y - h - 1, 0) * rowN + e];
+        out[(size_t)y * rowN + e] = (int16_t)s;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One wave per scan line of the cropped W1 x H domain, lane l owns disparities l*ND .. l*ND+ND-1.
 // L_r = C + min(L_r(p-r,d), L_r(p-r,d-1)+P1, L_r(p-r,d+1)+P1, minL_r(p-r)+P2) - (minL_r(p-r)+P2),
@@ -99,7 +155,7 @@ template <> struct CVec<2> { typedef u32 type; };
 template <> struct CVec<4> { typedef uint2 type; };
 template <> struct CVec<8> { typedef uint4 type; };
 
-struct PathArgs { const int16_t* C; int* acc; int H, W1, D, P1, P2; };
+struct PathArgs { const int16_t* C; int* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup; };
 
 // cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
 __device__ __forceinline__ int wave_shr1(int v, int fill)      // lane i <- lane i-1, lane 0 <- fill
@@ -117,9 +173,14 @@ __device__ __forceinline__ int wave_min_dpp(int v)
     return min(min(r0, r1), min(r2, r3));
 }
 
-template <int ND, bool FIRST>
+// FIRST: the group's first direction (nothing accumulated yet).  LAST: the group's last direction adds the group's sum
+// into S with 16-bit saturation (S = saturate(S + acc + L); the first group starts S at zero) instead of storing it.
+template <int ND, bool FIRST, bool LAST = false>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
+    // every element of S is read (several steps ahead) and later written by the same lane and by nobody else
+    const int16_t* __restrict__ Sin = a.S;
+    int16_t* __restrict__ Sout = a.S;
     const int lane = threadIdx.x & 63;
     const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (line >= nlines) return;
@@ -145,7 +206,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     // operands of step t + PF are requested when step t retires, so PF cost rows (and accumulator rows)
     // are in flight per wave while the serial recursion runs
     constexpr int PF = ND <= 2 ? 16 : 8;
-    struct In { V c; int old[ND]; };
+    struct In { V c; V sOld; int old[ND]; };
     In ring[PF];
     auto fetch = [&](int t, In& in) {
         if (!mine) return;
@@ -155,6 +216,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
             for (int j = 0; j < ND; j++) in.old[j] = a.acc[o + j];
         }
+        if (LAST && !a.firstGroup) in.sOld = *reinterpret_cast<const V*>(Sin + o);
     };
 #pragma unroll
     for (int u = 0; u < PF; u++)
@@ -184,9 +246,23 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         }
         mn = wave_min_dpp(mn);
         if (mine) {
-            int* ap = a.acc + ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
+            const size_t o = ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
+            if (LAST) {
+                int16_t sv[ND];
+                if (!a.firstGroup) __builtin_memcpy(sv, &ring[u].sOld, sizeof(V));
 #pragma unroll
-            for (int j = 0; j < ND; j++) ap[j] = old[j] + Ln[j];
+                for (int j = 0; j < ND; j++) {
+                    const int v = (a.firstGroup ? 0 : (int)sv[j]) + old[j] + Ln[j];
+                    sv[j] = (int16_t)min(max(v, -32768), 32767);
+                }
+                V packed;
+                __builtin_memcpy(&packed, sv, sizeof(V));
+                *reinterpret_cast<V*>(Sout + o) = packed;
+            } else {
+                int* ap = a.acc + o;
+#pragma unroll
+                for (int j = 0; j < ND; j++) ap[j] = old[j] + Ln[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
@@ -194,15 +270,6 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         if (t + PF < n) fetch(t + PF, ring[u]);
     }
     }
-}
-
-// S = saturate_cast<short>(S + acc)   (first group: S starts at zero)
-__global__ __launch_bounds__(256) void bt_saturate_kernel(const int* __restrict__ acc, size_t n, int first, int16_t* __restrict__ S)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int v = (first ? 0 : (int)S[i]) + acc[i];
-    S[i] = (int16_t)min(max(v, -32768), 32767);
 }
 
 struct SelArgs {
@@ -302,19 +369,43 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b)
         b = old;
     }
 }
-__global__ __launch_bounds__(256) void speckle_init_kernel(int* parent, int* count, int n)
+// Horizontal runs inside a wave's 64 columns are linked without atomics: every pixel starts out pointing at the first
+// pixel of its run (ballot of the run breaks + count-leading-zeros).
+__global__ __launch_bounds__(256) void speckle_init_kernel(const int16_t* __restrict__ img, int W, int newVal, int maxDiff, int* parent, int* count)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { parent[i] = i; count[i] = 0; }
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
+    const bool valid = x < W;
+    const int i = y * W + x;
+    const int v = valid ? (int)img[i] : newVal, l = (valid && x > 0) ? (int)img[i - 1] : newVal;
+    const bool joined = lane != 0 && v != newVal && l != newVal && abs(v - l) <= maxDiff;
+    const unsigned long long breaks = __ballot(!joined);                       // bit 0 is always set
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const int start = 63 - __clzll((long long)(breaks & upto));
+    if (valid) { parent[i] = i - (lane - start); count[i] = 0; }
 }
+// The remaining links: across wave boundaries of a row, and down to the next row.  A vertical link is skipped when the
+// pixel on the left and the one below it are linked to this pair and to each other: that neighbour (or one further
+// left, by induction) makes the same union.
 __global__ __launch_bounds__(256) void speckle_link_kernel(const int16_t* __restrict__ img, int H, int W, int newVal, int maxDiff, int* parent)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, lane = threadIdx.x & 63;
     if (x >= W) return;
     const int i = y * W + x, v = img[i];
     if (v == newVal) return;
-    if (x + 1 < W) { const int q = img[i + 1]; if (q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, i + 1); }
-    if (y + 1 < H) { const int q = img[i + W]; if (q != newVal && abs(v - q) <= maxDiff) uf_union(parent, i, i + W); }
+    const int l = x > 0 ? (int)img[i - 1] : newVal;
+    const bool joinedL = l != newVal && abs(v - l) <= maxDiff;
+    if (lane == 0 && joinedL) uf_union(parent, i - 1, i);
+    if (y + 1 < H) {
+        const int q = img[i + W];
+        if (q != newVal && abs(v - q) <= maxDiff) {
+            bool redundant = false;
+            if (lane != 0 && joinedL) {
+                const int lq = img[i - 1 + W];
+                redundant = lq != newVal && abs(q - lq) <= maxDiff && abs(l - lq) <= maxDiff;
+            }
+            if (!redundant) uf_union(parent, i, i + W);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __restrict__ img, int n, int newVal, int* parent, int* count)
 {
@@ -361,7 +452,7 @@ int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal
     const int n = H * W;
     int* parent = (int*)scratch;
     int* count = (int*)((u8*)scratch + md_align((size_t)n * 4, 256));
-    speckle_init_kernel<<<nblk(n), 256, 0, s>>>(parent, count, n);
+    speckle_init_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(img, W, newVal, maxDiff, parent, count);
     speckle_link_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(img, H, W, newVal, maxDiff, parent);
     speckle_count_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, parent, count);
     speckle_apply_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, maxSize, parent, count);
@@ -427,29 +518,37 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
-    bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
-    bt_window_kernel<false><<<gv, 256, 0, s>>>(v0, g, v1);
-    bt_window_kernel<true><<<gv, 256, 0, s>>>(v1, g, v0);          // v0 = block cost C
+    const size_t rowLds = (size_t)4 * cn * W;
+    if (rowLds <= 60 * 1024) {
+        bt_cost_hsum_kernel<<<dim3((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG), 256, rowLds, s>>>(pl1, pl2, g, v1);
+        bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
+    } else {
+        bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
+        bt_window_kernel<false><<<gv, 256, 0, s>>>(v0, g, v1);
+        bt_window_kernel<true><<<gv, 256, 0, s>>>(v1, g, v0);
+    }
     MD_HIP(hipGetLastError());
     if (dCost) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
     static const int DIRS[8][2] = {{+1, 0}, {+1, +1}, {0, +1}, {-1, +1}, {-1, 0}, {-1, -1}, {0, -1}, {+1, -1}};
-    PathArgs pa{v0, acc, H, g.W1, g.D, P1, P2};
+    PathArgs pa{v0, acc, H, g.W1, g.D, P1, P2, S, 1};
     const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
     for (int grp = 0; grp < 2; grp++) {
         const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
+        pa.firstGroup = grp == 0;
         for (int i = 0; i < ndir; i++) {
             const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
             const dim3 gp((nlines + 3) / 4);
-#define BT_PATH(NDV)                                                                        \
-            do {                                                                            \
-                if (i == 0) bt_path_kernel<NDV, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);  \
-                else bt_path_kernel<NDV, false><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
+#define BT_PATH(NDV)                                                                                     \
+            do {                                                                                         \
+                if (ndir == 1) bt_path_kernel<NDV, true, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);       \
+                else if (i == 0) bt_path_kernel<NDV, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);           \
+                else if (i == ndir - 1) bt_path_kernel<NDV, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
+                else bt_path_kernel<NDV, false><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                      \
             } while (0)
             if (nd == 1) BT_PATH(1); else if (nd == 2) BT_PATH(2); else if (nd == 4) BT_PATH(4); else BT_PATH(8);
 #undef BT_PATH
         }
-        bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
     }
     MD_HIP(hipGetLastError());
     SelArgs sa;

@@ -1,4 +1,5 @@
-"""rocprofv3 target: a few cv::StereoSGBM-replacement calls at 640x480, D=64 (the reference's call-site shape)."""
+"""rocprofv3 target: a few cv::StereoSGBM-replacement calls at 640x480, D=64 (the reference's call-site shape), or with
+the argument `1080p` at 1920x1080, D=256."""
 import ctypes as C
 import os
 import sys
@@ -11,6 +12,9 @@ from cameracalibration_amd import _lib, api  # noqa: E402
 lib = _lib.load()
 H, W = 480, 640
 args = (0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, 0)
+if len(sys.argv) > 1 and sys.argv[1] == "1080p":          # the benchmark's frame size and range
+    H, W = 1080, 1920
+    args = (0, 256, 7, 490, 1960, 1, 63, 10, 100, 32, 0)
 L, R, _ = api.synth_pair(0x5EED0001, H, W, args[1])
 dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
 out = torch.empty((H, W), dtype=torch.int16, device="cuda")
