@@ -155,7 +155,7 @@ template <> struct CVec<2> { typedef u32 type; };
 template <> struct CVec<4> { typedef uint2 type; };
 template <> struct CVec<8> { typedef uint4 type; };
 
-struct PathArgs { const int16_t* C; int* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup; };
+struct PathArgs { const int16_t* C; void* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup; };
 
 // cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
 __device__ __forceinline__ int wave_shr1(int v, int fill)      // lane i <- lane i-1, lane 0 <- fill
@@ -175,9 +175,11 @@ __device__ __forceinline__ int wave_min_dpp(int v)
 
 // FIRST: the group's first direction (nothing accumulated yet).  LAST: the group's last direction adds the group's sum
 // into S with 16-bit saturation (S = saturate(S + acc + L); the first group starts S at zero) instead of storing it.
-template <int ND, bool FIRST, bool LAST = false>
+// AccT: the group's running sum of up to three directions is kept as int16 when the cost bound allows it, else int32.
+template <int ND, bool FIRST, bool LAST = false, class AccT = int>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
+    AccT* const accp = static_cast<AccT*>(a.acc);
     // every element of S is read (several steps ahead) and later written by the same lane and by nobody else
     const int16_t* __restrict__ Sin = a.S;
     int16_t* __restrict__ Sout = a.S;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         in.c = *reinterpret_cast<const V*>(a.C + o);
         if (!FIRST) {
 #pragma unroll
-            for (int j = 0; j < ND; j++) in.old[j] = a.acc[o + j];
+            for (int j = 0; j < ND; j++) in.old[j] = accp[o + j];
         }
         if (LAST && !a.firstGroup) in.sOld = *reinterpret_cast<const V*>(Sin + o);
     };
@@ -259,9 +261,9 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 __builtin_memcpy(&packed, sv, sizeof(V));
                 *reinterpret_cast<V*>(Sout + o) = packed;
             } else {
-                int* ap = a.acc + o;
+                AccT* ap = accp + o;
 #pragma unroll
-                for (int j = 0; j < ND; j++) ap[j] = old[j] + Ln[j];
+                for (int j = 0; j < ND; j++) ap[j] = (AccT)(old[j] + Ln[j]);
             }
         }
 #pragma unroll
@@ -532,6 +534,10 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     static const int DIRS[8][2] = {{+1, 0}, {+1, +1}, {0, +1}, {-1, +1}, {-1, 0}, {-1, -1}, {0, -1}, {+1, -1}};
     PathArgs pa{v0, acc, H, g.W1, g.D, P1, P2, S, 1};
     const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
+    // a path value lies in [-P2, Cmax]; three of them fit int16 when the block cost cannot exceed 10922 (then it cannot
+    // have wrapped either): block cost <= bs^2 * cn * (2 * ftzero + 255 / 4)
+    const long cmax = (long)g.bs * g.bs * cn * (2 * g.ftzero + 63);
+    const bool acc16 = 3 * std::max<long>(cmax, P2) <= 32767;
     for (int grp = 0; grp < 2; grp++) {
         const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
         pa.firstGroup = grp == 0;
@@ -539,14 +545,15 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
             const dim3 gp((nlines + 3) / 4);
-#define BT_PATH(NDV)                                                                                     \
-            do {                                                                                         \
-                if (ndir == 1) bt_path_kernel<NDV, true, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);       \
-                else if (i == 0) bt_path_kernel<NDV, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);           \
-                else if (i == ndir - 1) bt_path_kernel<NDV, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
-                else bt_path_kernel<NDV, false><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                      \
+#define BT_PATH(NDV, ACC)                                                                                      \
+            do {                                                                                               \
+                if (ndir == 1) bt_path_kernel<NDV, true, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
+                else if (i == 0) bt_path_kernel<NDV, true, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
+                else if (i == ndir - 1) bt_path_kernel<NDV, false, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
+                else bt_path_kernel<NDV, false, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                \
             } while (0)
-            if (nd == 1) BT_PATH(1); else if (nd == 2) BT_PATH(2); else if (nd == 4) BT_PATH(4); else BT_PATH(8);
+            if (acc16) { if (nd == 1) BT_PATH(1, int16_t); else if (nd == 2) BT_PATH(2, int16_t); else if (nd == 4) BT_PATH(4, int16_t); else BT_PATH(8, int16_t); }
+            else { if (nd == 1) BT_PATH(1, int); else if (nd == 2) BT_PATH(2, int); else if (nd == 4) BT_PATH(4, int); else BT_PATH(8, int); }
 #undef BT_PATH
         }
     }

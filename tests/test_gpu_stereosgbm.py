@@ -28,6 +28,10 @@ CASES = [
     (30, 200, 1, (0, 128, 9, 100, 1000, 1, 0, 5, 0, 0, 0)),
     (20, 50, 1, (0, 64, 5)),                                               # narrower than the disparity range: all invalid
     (25, 300, 1, (1, 256, 3, 20, 80, 1, 20, 10, 20, 4, 1)),
+    (40, 120, 1, (0, 32, 7, 100, 10922, 1, 63, 10, 0, 0, 0)),              # largest P2 with 16-bit group sums
+    (40, 120, 1, (0, 32, 7, 100, 10923, 1, 63, 10, 0, 0, 1)),              # smallest P2 with 32-bit group sums
+    (36, 700, 1, (0, 64, 5, 50, 400, 1, 31, 10, 60, 2, 0)),                # several marching segments per row
+    (300, 100, 1, (0, 32, 9, 50, 400, 1, 31, 10, 60, 2, 1)),               # several marching bands per column
 ]
 
 
