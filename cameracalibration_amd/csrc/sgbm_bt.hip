@@ -281,6 +281,7 @@ struct SelArgs {
 // One workgroup per image row: first-minimum WTA, uniqueness, disp2 election (minimum S, ties to
 // the larger x: the library walks right to left with a strict '>'), x16 parabola, then the
 // disp12MaxDiff check.  Columns left of minX1 stay invalid.
+template <int ND>
 __global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
 {
     extern __shared__ u32 lds[];
@@ -291,15 +292,30 @@ __global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
     for (int i = threadIdx.x; i < W; i += 256) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // lane l holds the ND consecutive sums l*ND .. l*ND+ND-1 of a pixel (one vector load); D is a multiple of 16 >= ND
+    typedef typename CVec<ND>::type V;
+    const int k0 = lane * ND;
+    const bool mine = k0 < D;
+    V cur;
+    __builtin_memset(&cur, 0, sizeof(V));
+    if (mine && wv < a.W1) cur = *reinterpret_cast<const V*>(a.S + ((size_t)y * a.W1 + wv) * D + k0);
     for (int x1 = wv; x1 < a.W1; x1 += 4) {
         const int16_t* sp = a.S + ((size_t)y * a.W1 + x1) * D;
+        int16_t sv[ND];
+        __builtin_memcpy(sv, &cur, sizeof(V));
+        if (mine && x1 + 4 < a.W1) cur = *reinterpret_cast<const V*>(sp + (size_t)4 * D + k0);      // next pixel in flight
         u32 best = 0xFFFFFFFFu;
-        for (int k = lane; k < D; k += 64) best = min(best, ((u32)((int)sp[k] + 32768) << 16) | (u32)k);
+        if (mine) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) best = min(best, (u32)__shfl_xor((int)best, m, 64));
+            for (int j = 0; j < ND; j++) best = min(best, ((u32)((int)sv[j] + 32768) << 16) | (u32)(k0 + j));
+        }
+        best = (u32)wave_min_dpp((int)(best ^ 0x80000000u)) ^ 0x80000000u;      // unsigned minimum through the signed reduction
         const int bk = (int)(best & 0xFFFF), minS = (int)(best >> 16) - 32768;
         bool bad = false;
-        for (int k = lane; k < D; k += 64) bad |= ((int)sp[k] * (100 - a.uniq) < minS * 100) && (abs(bk - k) > 1);
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < ND; j++) bad |= ((int)sv[j] * (100 - a.uniq) < minS * 100) && (abs(bk - (k0 + j)) > 1);
+        }
         if (__any(bad)) continue;
         if (lane == 0) {
             int d = bk;
@@ -511,7 +527,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
         // (the median and speckle stages keep it constant)
         SelArgs sa{};
         sa.S = nullptr; sa.H = H; sa.W = W; sa.W1 = 0; sa.D = g.D; sa.minD = g.minD; sa.minX1 = W; sa.uniq = 0; sa.maxDiff = 1; sa.disp = dDisp;
-        bt_select_kernel<<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+        bt_select_kernel<1><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
         MD_HIP(hipGetLastError());
         if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, dDisp, N * 2, hipMemcpyDeviceToDevice, s));
         return MDISP_OK;
@@ -563,7 +579,10 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     sa.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
     sa.maxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     sa.disp = raw;
-    bt_select_kernel<<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    if (nd == 1) bt_select_kernel<1><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    else if (nd == 2) bt_select_kernel<2><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    else if (nd == 4) bt_select_kernel<4><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    else bt_select_kernel<8><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
     MD_HIP(hipGetLastError());
     if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, raw, N * 2, hipMemcpyDeviceToDevice, s));
     const bool speckle = p->speckleWindowSize > 0;
