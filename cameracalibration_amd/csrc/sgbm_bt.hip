@@ -7,6 +7,7 @@
 // is not part of the reference tree; its published algorithm is restated here (conventions listed
 // at the kernels).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restric
 // marches along the computed columns with a running sum (entering column - leaving column, both with the window
 // clamped to the computed columns), so the pixel costs never reach memory.  Same values as bt_cost_kernel followed by
 // bt_window_kernel<false>.
+#define BT_MULTI_MAX_UNITS ((size_t)96 << 20)   // cost-volume elements up to which a group's directions share one launch
 #define BT_SEG 128     // columns per marching segment of bt_cost_hsum_kernel
 #define BT_VBAND 120   // rows per marching band of bt_vsum_kernel
 __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
@@ -155,7 +157,10 @@ template <> struct CVec<2> { typedef u32 type; };
 template <> struct CVec<4> { typedef uint2 type; };
 template <> struct CVec<8> { typedef uint4 type; };
 
-struct PathArgs { const int16_t* C; void* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup; };
+struct PathArgs {
+    const int16_t* C; void* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup;
+    int mdx[4], mdy[4], mfirst[5];        // MULTI: the directions of one launch and the first line index of each
+};
 
 // cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
 __device__ __forceinline__ int wave_shr1(int v, int fill)      // lane i <- lane i-1, lane 0 <- fill
@@ -176,7 +181,10 @@ __device__ __forceinline__ int wave_min_dpp(int v)
 // FIRST: the group's first direction (nothing accumulated yet).  LAST: the group's last direction adds the group's sum
 // into S with 16-bit saturation (S = saturate(S + acc + L); the first group starts S at zero) instead of storing it.
 // AccT: the group's running sum of up to three directions is kept as int16 when the cost bound allows it, else int32.
-template <int ND, bool FIRST, bool LAST = false, class AccT = int>
+// MULTI: one launch runs the lines of all directions of a group side by side and adds their values into a zeroed
+// int32 `acc` with atomics (integer sums do not depend on the order) -- for small problems, where a single direction
+// has too few lines to fill the GPU and the serial recursion of each line sets the time.
+template <int ND, bool FIRST, bool LAST = false, class AccT = int, bool MULTI = false>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
     AccT* const accp = static_cast<AccT*>(a.acc);
@@ -184,8 +192,13 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     const int16_t* __restrict__ Sin = a.S;
     int16_t* __restrict__ Sout = a.S;
     const int lane = threadIdx.x & 63;
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int line = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (line >= nlines) return;
+    if (MULTI) {
+        int i = 0;
+        while (i < 3 && line >= a.mfirst[i + 1]) i++;
+        dx = a.mdx[i]; dy = a.mdy[i]; line -= a.mfirst[i];
+    }
     const int H = a.H, W = a.W1, D = a.D;
     int x0, y0;
     if (dy == 0) { y0 = line; x0 = dx > 0 ? 0 : W - 1; }
@@ -260,6 +273,10 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 V packed;
                 __builtin_memcpy(&packed, sv, sizeof(V));
                 *reinterpret_cast<V*>(Sout + o) = packed;
+            } else if (MULTI) {
+                int* ap = static_cast<int*>(a.acc) + o;
+#pragma unroll
+                for (int j = 0; j < ND; j++) atomicAdd(ap + j, Ln[j]);
             } else {
                 AccT* ap = accp + o;
 #pragma unroll
@@ -272,6 +289,15 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         if (t + PF < n) fetch(t + PF, ring[u]);
     }
     }
+}
+
+// S = saturate_cast<short>(S + acc)   (first group: S starts at zero)
+__global__ __launch_bounds__(256) void bt_saturate_kernel(const int* __restrict__ acc, size_t n, int first, int16_t* __restrict__ S)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int v = (first ? 0 : (int)S[i]) + acc[i];
+    S[i] = (int16_t)min(max(v, -32768), 32767);
 }
 
 struct SelArgs {
@@ -557,6 +583,24 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     for (int grp = 0; grp < 2; grp++) {
         const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
         pa.firstGroup = grp == 0;
+        if (ndir == 4 && V <= BT_MULTI_MAX_UNITS && !getenv("MDISP_SGBM_BT_SEQUENTIAL")) {
+            // small problem: the four directions of the group in one launch
+            int total = 0;
+            for (int i = 0; i < 4; i++) {
+                pa.mdx[i] = DIRS[grp * 4 + i][0]; pa.mdy[i] = DIRS[grp * 4 + i][1];
+                pa.mfirst[i] = total;
+                total += pa.mdy[i] == 0 ? H : (pa.mdx[i] == 0 ? g.W1 : g.W1 + H - 1);
+            }
+            pa.mfirst[4] = total;
+            MD_HIP(hipMemsetAsync(acc, 0, V * 4, s));
+            const dim3 gm((total + 3) / 4);
+            if (nd == 1) bt_path_kernel<1, true, false, int, true><<<gm, 256, 0, s>>>(pa, 0, 0, total);
+            else if (nd == 2) bt_path_kernel<2, true, false, int, true><<<gm, 256, 0, s>>>(pa, 0, 0, total);
+            else if (nd == 4) bt_path_kernel<4, true, false, int, true><<<gm, 256, 0, s>>>(pa, 0, 0, total);
+            else bt_path_kernel<8, true, false, int, true><<<gm, 256, 0, s>>>(pa, 0, 0, total);
+            bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
+            continue;
+        }
         for (int i = 0; i < ndir; i++) {
             const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);

@@ -35,8 +35,19 @@ CASES = [
 ]
 
 
+# small problems run the four directions of a group in one launch; large ones one direction per launch with the
+# running group sum kept in memory -- the environment switch selects the second schedule at test sizes
+@pytest.fixture(params=["one launch per group", "one launch per direction"])
+def bt_schedule(request, monkeypatch):
+    if request.param == "one launch per direction":
+        monkeypatch.setenv("MDISP_SGBM_BT_SEQUENTIAL", "1")
+    else:
+        monkeypatch.delenv("MDISP_SGBM_BT_SEQUENTIAL", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_stereosgbm_bit_exact(api, orc, case):
+def test_stereosgbm_bit_exact(api, orc, case, bt_schedule):
     H, W, cn, args = case
     L, R = _pair(api, 0x5EED0001 + H, H, W, max(args[1] // 2, 8), cn)
     p = api.StereoSGBM_create(*args)
