@@ -601,6 +601,18 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
             continue;
         }
+        if (ndir == 1 && V <= BT_MULTI_MAX_UNITS && !getenv("MDISP_SGBM_BT_SEQUENTIAL")) {
+            // small problem, single direction: its serial chain is shorter without the read-modify-write of S
+            const int dx = DIRS[grp * 4][0], dy = DIRS[grp * 4][1];
+            const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
+            const dim3 gp((nlines + 3) / 4);
+            if (nd == 1) bt_path_kernel<1, true, false, int><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);
+            else if (nd == 2) bt_path_kernel<2, true, false, int><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);
+            else if (nd == 4) bt_path_kernel<4, true, false, int><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);
+            else bt_path_kernel<8, true, false, int><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);
+            bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
+            continue;
+        }
         for (int i = 0; i < ndir; i++) {
             const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
