@@ -379,6 +379,27 @@ __global__ __launch_bounds__(256) void out_wta_kernel(OutArgs a)
 // the means; a_bar*G + b_bar from the second pair of means) runs in the store functor.
 // Window: starts at p - ksz/2; mode 0: ksz taps, BORDER_REFLECT_101; mode 1: 2*(ksz/2) taps, zero
 // outside [0, n-1) (the clipped half-open window of getGuidedFilter_skwgif2, gifs.cpp:591-592).
+// inclusive prefix sum of a double over the 64 lanes of a wave on the DPP path (no LDS crossbar round trips):
+// shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the row totals are broadcast into the following rows
+template <int CTRL, int ROWMASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROWMASK, 0xF, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROWMASK, 0xF, BOUND);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_scan_f64(double s)
+{
+    s += dpp_f64<0x111, 0xF, true>(s);      // row_shr:1
+    s += dpp_f64<0x112, 0xF, true>(s);      // row_shr:2
+    s += dpp_f64<0x114, 0xF, true>(s);      // row_shr:4
+    s += dpp_f64<0x118, 0xF, true>(s);      // row_shr:8
+    s += dpp_f64<0x142, 0xA, false>(s);     // row_bcast:15 into rows 1 and 3
+    s += dpp_f64<0x143, 0xC, false>(s);     // row_bcast:31 into rows 2 and 3
+    return s;
+}
+
 #define MW 128
 struct MarchGeom { int H, W, ksz, mode, band; int yA, yB; };   // output rows [yA, yB) of the image
 
@@ -449,11 +470,7 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
         const double2 e0 = *reinterpret_cast<const double2*>(&dd0[2 * tx]);
         const double2 e1 = *reinterpret_cast<const double2*>(&dd1[2 * tx]);
         double s0 = e0.x + e0.y, s1 = e1.x + e1.y;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
-            if (lane >= d) { s0 += u0; s1 += u1; }
-        }
+        s0 = wave_scan_f64(s0); s1 = wave_scan_f64(s1);
         if (lane == 63) { wtot[wave][0] = s0; wtot[wave][1] = s1; }
         __syncthreads();
         if (wave == 1) { s0 += wtot[0][0]; s1 += wtot[0][1]; }
