@@ -45,40 +45,65 @@ struct BmGeom {
     int ymin, Hv;            // first valid row and number of valid rows
 };
 
-// hs[y][d][xv] (d = 0..ndisp-1 candidates in the library's order: disparity = ndisp-1-d+mind; d = ndisp: texture)
+// hs[y][d][xv] (d = 0..ndisp-1 candidates in the library's order: disparity = ndisp-1-d+mind; d = ndisp: texture).
+// The two row segments sit in LDS as bytes; a window is summed four taps at a time with v_sad_u8 on words assembled from
+// aligned LDS dwords by v_alignbyte (the byte offset of a lane's window is not a multiple of four).
 __global__ __launch_bounds__(256) void bm_hsum_kernel(const u8* Lp, const u8* Rp, size_t pitch, BmGeom g, u16* hs)
 {
-    extern __shared__ u8 lds[];
+    extern __shared__ u32 ldsw[];
+    u8* lds = reinterpret_cast<u8*>(ldsw);
     const int w = g.w, wsz = 2 * w + 1;
     const int nL = 256 + 2 * w, nR = nL + g.ndisp - 1;
+    const int offR = (nL + 8 + 3) & ~3;                    // 8 bytes of slack: the last word of a window may start a dword early
     u8* Ls = lds;
-    u8* Rs = lds + ((nL + 3) & ~3);
+    u8* Rs = lds + offR;
     const int y = blockIdx.y, xv0 = blockIdx.x * 256;
     const int X0 = g.xmin + xv0;                           // image column of this block's first output
     const int maxD = g.mind + g.ndisp - 1;
     // left columns [X0 - w, X0 + 255 + w]; right columns start maxD further left (candidate d = 0 is the largest disparity)
-    for (int i = threadIdx.x; i < nL; i += 256) {
+    for (int i = threadIdx.x; i < nL + 8; i += 256) {
         const int X = X0 - w + i;
-        Ls[i] = X < g.W ? Lp[(size_t)y * pitch + X] : 0;
+        Ls[i] = (i < nL && X < g.W) ? Lp[(size_t)y * pitch + X] : 0;
     }
-    for (int i = threadIdx.x; i < nR; i += 256) {
+    for (int i = threadIdx.x; i < nR + 8; i += 256) {
         const int X = X0 - w - maxD + i;
-        Rs[i] = (X >= 0 && X < g.W) ? Rp[(size_t)y * pitch + X] : 0;
+        Rs[i] = (i < nR && X >= 0 && X < g.W) ? Rp[(size_t)y * pitch + X] : 0;
     }
     __syncthreads();
     const int xv = xv0 + threadIdx.x;
     if (xv >= g.Wv) return;
     u16* out = hs + ((size_t)y * (g.ndisp + 1)) * g.Wv + xv;
-    const u8* l = Ls + threadIdx.x;
+    const u32* Lw = ldsw;
+    const u32* Rw = ldsw + (offR >> 2);
+    const int nW = (wsz + 3) >> 2, rem = wsz - 4 * (nW - 1);
+    const u32 tailMask = rem == 4 ? 0xFFFFFFFFu : ((1u << (8 * rem)) - 1u);
+    const int t = threadIdx.x, wl = t >> 2, shl = t & 3;
+    auto word = [](u32 hi, u32 lo, int sh) -> u32 {          // bytes sh .. sh+3 of the pair (lo, hi)
+        return sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1) : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
+                                                                                     : __builtin_amdgcn_alignbyte(hi, lo, 3);
+    };
     for (int d = 0; d < g.ndisp; d++) {
-        const u8* r = Rs + threadIdx.x + d;                // right column = left column - (ndisp-1-d+mind)
-        int s = 0;
-        for (int i = 0; i < wsz; i++) s += abs((int)l[i] - (int)r[i]);
+        const int ob = t + d, wr = ob >> 2, shr = ob & 3;   // right column = left column - (ndisp-1-d+mind)
+        u32 lprev = Lw[wl], rprev = Rw[wr], s = 0;
+        for (int k = 0; k < nW; k++) {
+            const u32 lnext = Lw[wl + k + 1], rnext = Rw[wr + k + 1];
+            u32 lv = word(lnext, lprev, shl), rv = word(rnext, rprev, shr);
+            if (k == nW - 1) { lv &= tailMask; rv &= tailMask; }
+            s = __builtin_amdgcn_sad_u8(lv, rv, s);
+            lprev = lnext; rprev = rnext;
+        }
         out[(size_t)d * g.Wv] = (u16)s;
     }
-    int t = 0;
-    for (int i = 0; i < wsz; i++) t += abs((int)l[i] - g.cap);
-    out[(size_t)g.ndisp * g.Wv] = (u16)t;
+    u32 lprev = Lw[wl], tx = 0;
+    const u32 capw = (u32)g.cap * 0x01010101u;
+    for (int k = 0; k < nW; k++) {
+        const u32 lnext = Lw[wl + k + 1];
+        u32 lv = word(lnext, lprev, shl), cv = capw;
+        if (k == nW - 1) { lv &= tailMask; cv &= tailMask; }
+        tx = __builtin_amdgcn_sad_u8(lv, cv, tx);
+        lprev = lnext;
+    }
+    out[(size_t)g.ndisp * g.Wv] = (u16)tx;
 }
 
 constexpr int BM_DPT = 32;      // candidates per thread
@@ -272,7 +297,7 @@ int md_stereobm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitchIn, i
     bm_xsobel_kernel<<<gp, 256, 0, s>>>(dL, pitchIn, H, W, g.cap, Lp, pitch);
     bm_xsobel_kernel<<<gp, 256, 0, s>>>(dR, pitchIn, H, W, g.cap, Rp, pitch);
     const int nL = 256 + 2 * g.w;
-    const size_t ldsH = ((nL + 3) & ~3) + nL + g.ndisp;
+    const size_t ldsH = (((nL + 8 + 3) & ~3) + nL + g.ndisp + 8 + 3) & ~(size_t)3;
     bm_hsum_kernel<<<dim3((g.Wv + 255) / 256, H), 256, ldsH, s>>>(Lp, Rp, pitch, g, hs);
     const int NW = (g.ndisp + BM_DPT - 1) / BM_DPT;
     const size_t ldsV = (size_t)(3 * 2 * NW * 64 + 2 * 2 * 64) * sizeof(int);
