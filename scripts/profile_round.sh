@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r01f
+O=$GRAFT_REPO_ROOT/gpurun_out/r01g
 rm -rf $O; mkdir -p $O
 timeout -k 10 240 python3 bench.py > $O/bench.json 2> $O/bench.err
 cat $O/bench.json
