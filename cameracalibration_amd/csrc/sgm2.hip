@@ -582,6 +582,9 @@ struct ShearArgs {
     int nsh, cmin, batch;
 };
 constexpr int SHEAR_SPIN_LIMIT = 1 << 22;
+// compute lanes of a sheared-sweep workgroup (+ one communication wave), i.e. strips of NT / LPC columns: 256 lanes for
+// large batches (a row barrier over five waves), 512 for small batches and for the five-path mode (half as many strips:
+// half the hand-off traffic and half the pipeline ramp, at the price of a row barrier over nine waves)
 
 __device__ __forceinline__ void hand_store(u8* p, const uint4& v)
 {
@@ -597,11 +600,11 @@ __device__ __forceinline__ uint4 hand_load(const u8* p)
     return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
-template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, bool FIVE = false>
-__global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
+template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, bool FIVE = false, int SHEAR_NT = 256>
+__global__ __launch_bounds__(SHEAR_NT + 64) void sgm2_shear_kernel(ShearArgs sa)
 {
-    // LPC lanes share a pixel (16 disparities each); a strip is CW = 256/LPC sheared columns wide
-    constexpr int CW = 256 / LPC, DP = LPC * DPL, SW = LPC * 4;
+    // LPC lanes share a pixel (16 disparities each); a strip is CW = SHEAR_NT/LPC sheared columns wide
+    constexpr int CW = SHEAR_NT / LPC, DP = LPC * DPL, SW = LPC * 4;
     const Sgm2Args& a = sa.a;
     __shared__ u32 vs[2][CW][SW];      // vertical-path states of the previous / current row, as bytes
     __shared__ u32 bs[2][CW][SW];      // states of the diagonal that crosses two sheared columns per row
@@ -629,11 +632,11 @@ __global__ __launch_bounds__(320) void sgm2_shear_kernel(ShearArgs sa)
         return hand + ((((size_t)y * sa.nsh + strip) * 3 + which) * DP + lic * 16);
     };
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= SHEAR_NT) {
         // ---- communication wave: publishes this strip's edge states one row behind the compute
         // waves and fetches the neighbour's one row ahead of them, so that neither the write-through
         // drain nor a wait for a slow neighbour sits in the compute waves' instruction stream
-        const int lane = threadIdx.x - 256, which = lane / LPC, lic = lane % LPC;
+        const int lane = threadIdx.x - SHEAR_NT, which = lane / LPC, lic = lane % LPC;
         int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
         const int* progNb = progMe + (UP ? -1 : 1);
         int* errWord = sa.sync + 2;
@@ -940,9 +943,15 @@ static int lanes_per_pixel(const md_sgm_plan& pl)
 int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
 
 static int shear_strips(int H, int W, int cw) { return (W + H - 1 + cw - 1) / cw; }
-static size_t shear_hand_bytes(int H, int W, int lpc) { return md_align((size_t)H * shear_strips(H, W, 256 / lpc) * 3 * lpc * DPL, 256); }
-static size_t shear_sync_bytes(int H, int W, int batch, int lpc)
-{ return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, 256 / lpc)) * sizeof(int), 256); }
+static int shear_nt(const md_sgm_plan& pl, int batch)
+{
+    const char* e = getenv("MDISP_SGM_STRIP_LANES");
+    if (e) return atoi(e) == 512 ? 512 : 256;
+    return (pl.npaths == 5 || batch <= 32) ? 512 : 256;
+}
+static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
+static size_t shear_sync_bytes(int H, int W, int batch, int lpc, int nt)
+{ return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, nt / lpc)) * sizeof(int), 256); }
 
 struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, slots, mode, cw; bool u8m; };
 static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
@@ -954,12 +963,12 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
     l.slots = l.lpc * DPL;
     l.cw = CW;
     l.nstrips = (pl.W + l.cw - 1) / l.cw;
-    if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc); }   // hand-off rows
+    if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // hand-off rows (sized for the narrower strips)
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
     l.oneS2 = l.mode == SGM2_SPLIT ? md_align((size_t)pl.H * pl.W * 256 * sizeof(u16), 256) : 0;
-    l.syncBytes = shear_sync_bytes(pl.H, pl.W, batch, l.lpc);
+    l.syncBytes = shear_sync_bytes(pl.H, pl.W, batch, l.lpc, 256);
     return l;
 }
 
@@ -978,7 +987,7 @@ bool md_sgm2_supported(const md_sgm_plan& pl)
 bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
 
 namespace {
-template <int LPC>
+template <int LPC, int NT>
 int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int batch, int naturalOut)
 {
     const Sgm2Args& a = sa.a;
@@ -987,17 +996,17 @@ int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int 
 #define SGM2_SHEAR(TAILV, S4BV)                                                                           \
     do {                                                                                                  \
         sgm2_hscan_kernel<TAILV, true, LPC><<<gh, 256, 0, s>>>(a);                                        \
-        sgm2_shear_kernel<false, TAILV, false, S4BV, LPC><<<gs, 320, 0, s>>>(sa);                         \
-        if (naturalOut) sgm2_shear_kernel<true, TAILV, false, S4BV, LPC><<<gs, 320, 0, s>>>(sa);          \
-        else sgm2_shear_kernel<true, TAILV, true, S4BV, LPC><<<gs, 320, 0, s>>>(sa);                      \
+        sgm2_shear_kernel<false, TAILV, false, S4BV, LPC, false, NT><<<gs, NT + 64, 0, s>>>(sa);             \
+        if (naturalOut) sgm2_shear_kernel<true, TAILV, false, S4BV, LPC, false, NT><<<gs, NT + 64, 0, s>>>(sa); \
+        else sgm2_shear_kernel<true, TAILV, true, S4BV, LPC, false, NT><<<gs, NT + 64, 0, s>>>(sa);           \
     } while (0)
     // the down sweep's four-path sum stays below 256 for small P2: half the volume traffic
     const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
     if (a.five) {
         // -> and <- from the horizontal scan, the three downward paths and the winner-take-all in ONE sweep
         sgm2_hscan_kernel<true, true, LPC><<<gh, 256, 0, s>>>(a);
-        if (naturalOut) sgm2_shear_kernel<false, true, false, false, LPC, true><<<gs, 320, 0, s>>>(sa);
-        else sgm2_shear_kernel<false, true, true, false, LPC, true><<<gs, 320, 0, s>>>(sa);
+        if (naturalOut) sgm2_shear_kernel<false, true, false, false, LPC, true, NT><<<gs, NT + 64, 0, s>>>(sa);
+        else sgm2_shear_kernel<false, true, true, false, LPC, true, NT><<<gs, NT + 64, 0, s>>>(sa);
     } else if (a.tail) { if (s4b) SGM2_SHEAR(true, true); else SGM2_SHEAR(true, false); }
     else { if (s4b) SGM2_SHEAR(false, true); else SGM2_SHEAR(false, false); }
 #undef SGM2_SHEAR
@@ -1065,12 +1074,19 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         sa.a = a;
         sa.hand = extra; sa.strideHand = l.bndBytes;
         sa.sync = (int*)afterRec;
-        sa.nsh = shear_strips(pl.H, pl.W, 256 / l.lpc); sa.cmin = -(pl.H - 1); sa.batch = batch;
+        const int nt = shear_nt(pl, batch);
+        sa.nsh = shear_strips(pl.H, pl.W, nt / l.lpc); sa.cmin = -(pl.H - 1); sa.batch = batch;
         MD_HIP(hipMemsetAsync(sa.sync, 0, l.syncBytes, s));
         if (errWord) *errWord = sa.sync + 2;
-        if (l.lpc == 4) MD_TRY(launch_shear<4>(s, pl, sa, batch, naturalOut));
-        else if (l.lpc == 8) MD_TRY(launch_shear<8>(s, pl, sa, batch, naturalOut));
-        else MD_TRY(launch_shear<16>(s, pl, sa, batch, naturalOut));
+        if (nt == 512) {
+            if (l.lpc == 4) MD_TRY((launch_shear<4, 512>(s, pl, sa, batch, naturalOut)));
+            else if (l.lpc == 8) MD_TRY((launch_shear<8, 512>(s, pl, sa, batch, naturalOut)));
+            else MD_TRY((launch_shear<16, 512>(s, pl, sa, batch, naturalOut)));
+        } else {
+            if (l.lpc == 4) MD_TRY((launch_shear<4, 256>(s, pl, sa, batch, naturalOut)));
+            else if (l.lpc == 8) MD_TRY((launch_shear<8, 256>(s, pl, sa, batch, naturalOut)));
+            else MD_TRY((launch_shear<16, 256>(s, pl, sa, batch, naturalOut)));
+        }
     } else {
     dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
