@@ -924,7 +924,7 @@ enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2 };
 static int split_max_batch()
 {
     const char* e = getenv("MDISP_SGM_SPLIT_MAX");
-    return e ? atoi(e) : 4;
+    return e ? atoi(e) : 3;      // from 4 pairs on the strip pipeline (512-lane strips) is faster
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
