@@ -343,12 +343,23 @@ __global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
             for (int j = 0; j < ND; j++) bad |= ((int)sv[j] * (100 - a.uniq) < minS * 100) && (abs(bk - (k0 + j)) > 1);
         }
         if (__any(bad)) continue;
+        // the neighbours of the minimum for the parabola, from the registers that hold them (the minimum is the same in
+        // every lane, so lane and register index are wave-uniform): no dependent memory access in this serial loop
+        auto s_at = [&](int k) -> int {
+            const int kk = __builtin_amdgcn_readfirstlane(min(max(k, 0), D - 1));
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < ND; j++)
+                if (j == kk % ND) v = sv[j];
+            return __builtin_amdgcn_readlane(v, kk / ND);
+        };
+        const int sm = s_at(bk - 1), spl = s_at(bk + 1);
         if (lane == 0) {
             int d = bk;
             const int x = x1 + a.minX1, x2 = x - d - a.minD;
             atomicMin(&key[x2], ((best >> 16) << 16) | (u32)(0xFFFF - x));
             if (d > 0 && d < D - 1) {
-                const int sm = sp[d - 1], s0 = sp[d], spl = sp[d + 1];
+                const int s0 = minS;
                 const int den = max(sm + spl - 2 * s0, 1);
                 d = d * 16 + ((sm - spl) * 16 + den) / (den * 2);
             } else d *= 16;
