@@ -11,6 +11,27 @@ typedef unsigned int u32;
                 asm volatile(INS " %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 3) & 7]));      \
         }                                                                                           \
     }
+#define BODY2(INS)                                                                                  \
+    for (int it = 0; it < iters; it++) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                             \
+            _Pragma("unroll") for (int i = 0; i < 8; i++)                                           \
+                asm volatile(INS " %0, %1" : "=v"(a[i]) : "v"(a[(i + 3) & 7]));                     \
+        }                                                                                           \
+    }
+#define BODY4P(INS)                                                                                 \
+    for (int it = 0; it < iters; it++) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                           \
+                asm volatile(INS " %0, %1, %2, %3" : "=v"(b[i]) : "v"(b[i]), "v"(b[(i + 1) & 3]), "v"(b[(i + 2) & 3])); \
+        }                                                                                           \
+    }
+#define BODY3P(INS)                                                                                 \
+    for (int it = 0; it < iters; it++) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                           \
+                asm volatile(INS " %0, %1, %2" : "=v"(b[i]) : "v"(b[i]), "v"(b[(i + 1) & 3]));      \
+        }                                                                                           \
+    }
 #define BODY4(INS)                                                                                  \
     for (int it = 0; it < iters; it++) {                                                            \
         _Pragma("unroll") for (int u = 0; u < 8; u++) {                                             \
@@ -44,6 +65,15 @@ __global__ __launch_bounds__(256) void k(u32* out, int iters, u32 seed)
     if (OP == 17) BODY4("v_bfe_u32")
     if (OP == 18) BODY3("v_lshlrev_b32")
     if (OP == 19) BODY4("v_mad_u32_u24")
+    unsigned long long b[4];
+    for (int i = 0; i < 4; i++) b[i] = ((unsigned long long)a[i] << 32) | a[i + 4];
+    if (OP == 20) BODY2("v_exp_f32")
+    if (OP == 21) BODY2("v_rcp_f32")
+    if (OP == 22) BODY4P("v_pk_fma_f32")
+    if (OP == 23) BODY3P("v_pk_mul_f32")
+    if (OP == 24) BODY3P("v_pk_add_f32")
+    if (OP == 25) BODY4("v_fma_f32")
+    for (int i = 0; i < 4; i++) a[i] ^= (u32)b[i] ^ (u32)(b[i] >> 32);
     u32 s = 0;
     for (int i = 0; i < 8; i++) s ^= a[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -75,6 +105,8 @@ int main()
         run<8>("v_perm_b32", w); run<9>("v_bcnt_u32_b32", w); run<10>("v_and_b32", w); run<11>("v_lshl_or_b32", w);
         run<12>("v_alignbit_b32", w); run<13>("v_min3_u32", w); run<14>("v_pk_mad_u16", w); run<15>("v_xor_b32", w);
         run<16>("v_and_or_b32", w); run<17>("v_bfe_u32", w); run<18>("v_lshlrev_b32", w); run<19>("v_mad_u32_u24", w);
+        run<20>("v_exp_f32", w); run<21>("v_rcp_f32", w); run<25>("v_fma_f32", w);
+        run<22>("v_pk_fma_f32 (x0.5)", w); run<23>("v_pk_mul_f32 (x0.5)", w); run<24>("v_pk_add_f32 (x0.5)", w);
         }
     }
     return 0;
