@@ -557,6 +557,121 @@ __global__ __launch_bounds__(256) void sgm2_sweep_kernel(Sgm2Args a)
     }
 }
 
+// Latency variant of sgm2_sweep_kernel for the smallest batches (byte path states, four-path sums that fit a byte):
+// the three paths of a sweep run on three groups of four waves, so the serial chain of a row is one path step
+// instead of three.  Every group evaluates the matching cost itself.  Group 0 runs the vertical path and keeps
+// the row's partial sum (horizontal volume + vertical path, as bytes); groups 1 and 2 run the two diagonals,
+// exchange their states through LDS as the one-group kernel does, and leave their path values in LDS, where
+// group 0 picks them up one row later, adds them and stores the four-path sum as 16 bytes per lane.
+inline __device__ uint4 add4(const uint4& p, const uint4& q) { return make_uint4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w); }
+
+template <bool UP, bool TAIL, int PFD = 4>
+__global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
+{
+    __shared__ u32 diag[2][2][CW][64];    // [row parity][diagonal][column]: normalised states, bytes
+    __shared__ u32 part[2][2][CW][64];    // [row parity][diagonal][column]: path values, bytes
+    const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int lic = t & 15, lr = t >> 4;
+    const int strip = blockIdx.x, pair = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int x0 = strip * CW;
+    const int cw = min(CW, W - x0);
+    const int x = x0 + lr;
+    const bool colActive = lr < cw;
+    const u8* cLp = a.cL + (size_t)pair * a.strideL;
+    const u8* cRp = a.cR + (size_t)pair * a.strideR;
+    u8* Sp = reinterpret_cast<u8*>((UP ? a.S2 : a.S) + (size_t)pair * a.strideS);
+    const u8* Hp = a.Hvol[UP ? 1 : 0] + (size_t)pair * a.strideH;
+    // group 1: diagonal with dx = +1 (predecessor at x-1), group 2: dx = -1 (predecessor at x+1)
+    const u16* bnd = a.bnd[(UP ? 2 : 0) + (grp == 2 ? 1 : 0)] + (size_t)pair * a.strideB;
+    const int fam = grp == 2 ? 1 : 0;
+    const int nbCol = grp == 2 ? lr + 1 : lr - 1;
+    const bool atBorder = grp == 2 ? x == W - 1 : x == 0;                                  // the path starts at this pixel
+    const bool atEdge = !atBorder && (grp == 2 ? lr == cw - 1 : lr == 0);                   // predecessor in the next strip
+    u32 tail[NR];
+    make_tail(lic, a.D, tail);
+    const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
+    const int sy = UP ? -1 : 1, ys = UP ? H - 1 : 0;
+
+    u32 N[NR];
+    zero8(N);
+    if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) N[r] |= tail[r];
+    }
+    // a row is a short chain now, so operands are requested PFD rows ahead
+    struct RowIn { u32 cl; uint4 rb, hb; u32 Bn[NR]; };
+    RowIn ring[PFD];
+    auto fetch_row = [&](int r, RowIn& in) {
+        const int y = ys + sy * r;
+        load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, in.cl, in.rb);
+        if (grp == 0) in.hb = *reinterpret_cast<const uint4*>(Hp + ((size_t)y * W + x) * 256 + lic * 16);
+        else if (r > 0 && atEdge) load8(bnd + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), in.Bn);
+    };
+#pragma unroll
+    for (int u = 0; u < PFD; u++) {
+        ring[u].cl = 0; ring[u].rb = make_uint4(0, 0, 0, 0); ring[u].hb = make_uint4(0, 0, 0, 0);
+        zero8(ring[u].Bn);
+        if (colActive && u < H) fetch_row(u, ring[u]);
+    }
+    uint4 pend = make_uint4(0, 0, 0, 0);      // group 0: horizontal + vertical bytes of the previous row
+    auto process_row = [&](int r, RowIn& in) {
+        const int y = ys + sy * r, par = r & 1;
+        if (colActive) {
+            u32 C[NR], L[NR], Bc[NR];
+            cost_from_operands(in.cl, in.rb, C);
+            const uint4 hcur = in.hb;
+#pragma unroll
+            for (int q = 0; q < NR; q++) Bc[q] = in.Bn[q];
+            if (r + PFD < H) fetch_row(r + PFD, in);
+            if (grp == 0) {
+                if (r > 0) {
+                    const uint4 pa = *reinterpret_cast<const uint4*>(&part[par ^ 1][0][lr][lic * 4]);
+                    const uint4 pb = *reinterpret_cast<const uint4*>(&part[par ^ 1][1][lr][lic * 4]);
+                    store16_stream(Sp + ((size_t)(y - sy) * W + x) * 256 + lic * 16, add4(pend, add4(pa, pb)));
+                }
+                sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+                pend = add4(hcur, pack_bytes(L));
+            } else {
+                if (r == 0 || atBorder) {
+                    zero8(N);
+                    if (TAIL) {
+#pragma unroll
+                        for (int q = 0; q < NR; q++) N[q] |= tail[q];
+                    }
+                } else if (!atEdge) {
+                    unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][fam][nbCol][lic * 4]), N);
+                    if (TAIL) {   // the byte form drops the "infinite" marker of disparities >= D
+#pragma unroll
+                        for (int q = 0; q < NR; q++) N[q] |= tail[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NR; q++) N[q] = Bc[q];
+                }
+                sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+                *reinterpret_cast<uint4*>(&diag[par][fam][lr][lic * 4]) = pack_bytes(N);
+                *reinterpret_cast<uint4*>(&part[par][fam][lr][lic * 4]) = pack_bytes(L);
+            }
+        }
+        __syncthreads();   // diag[par] and part[par] complete before the next row reads them
+    };
+    for (int r0 = 0; r0 < H; r0 += PFD) {
+#pragma unroll
+        for (int u = 0; u < PFD; u++) {
+            const int r = r0 + u;
+            if (r >= H) break;
+            process_row(r, ring[u]);
+        }
+    }
+    if (colActive && grp == 0) {
+        const int par = (H - 1) & 1, y = ys + sy * (H - 1);
+        const uint4 pa = *reinterpret_cast<const uint4*>(&part[par][0][lr][lic * 4]);
+        const uint4 pb = *reinterpret_cast<const uint4*>(&part[par][1][lr][lic * 4]);
+        store16_stream(Sp + ((size_t)y * W + x) * 256 + lic * 16, add4(pend, add4(pa, pb)));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sheared sweep (byte-state mode only): the same three paths per sweep as sgm2_sweep_kernel, but a
 // workgroup owns 256/LPC columns of the SHEARED frame c = x - y.  In that frame
@@ -827,7 +942,7 @@ __global__ __launch_bounds__(SHEAR_NT + 64) void sgm2_shear_kernel(ShearArgs sa)
 // Split mode (small batches): the down and the up sweep run side by side on two streams and each
 // stores its four-path sum (register order); this kernel adds the two and runs the winner-take-all.
 // One workgroup per image row.
-template <bool TAIL>
+template <bool TAIL, bool BYTES = false>
 __global__ __launch_bounds__(256) void sgm2_wta_sum_kernel(Sgm2Args a)
 {
     __shared__ u32 srow[CW][128];
@@ -845,8 +960,15 @@ __global__ __launch_bounds__(256) void sgm2_wta_sum_kernel(Sgm2Args a)
         if (x < W) {
             const size_t pix = (size_t)y * W + x;
             u32 A[NR], B[NR];
-            load8_stream(Sa + (pix * 256 + lic * DPL), A);
-            load8_stream(Sb + (pix * 256 + lic * DPL), B);
+            if (BYTES) {      // four-path sums stored as bytes by sgm2_sweep3_kernel
+                const uint4 wa = load16_stream(reinterpret_cast<const u8*>(Sa) + pix * 256 + lic * 16);
+                const uint4 wb = load16_stream(reinterpret_cast<const u8*>(Sb) + pix * 256 + lic * 16);
+                unpack_bytes(wa, A);
+                unpack_bytes(wb, B);
+            } else {
+                load8_stream(Sa + (pix * 256 + lic * DPL), A);
+                load8_stream(Sb + (pix * 256 + lic * DPL), B);
+            }
 #pragma unroll
             for (int q = 0; q < NR; q++) A[q] = pkadd(A[q], B[q]);
             fused_wta<TAIL>(a, A, tail, lic, &srow[lr][0], exclMask, (size_t)pair * a.strideRec + pix);
@@ -925,6 +1047,11 @@ static int split_max_batch()
 {
     const char* e = getenv("MDISP_SGM_SPLIT_MAX");
     return e ? atoi(e) : 3;      // from 4 pairs on the strip pipeline (512-lane strips) is faster
+}
+static int path_waves_max_batch()
+{
+    const char* e = getenv("MDISP_SGM_PATH_WAVES_MAX");
+    return e ? atoi(e) : 3;      // largest batch whose sweeps run one path per wave group (every batch of the latency schedule)
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
@@ -1066,7 +1193,24 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             if (aux) { MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0)); }  \
             sgm2_wta_sum_kernel<TAILV><<<dim3(pl.H, batch), 256, 0, s>>>(a);                     \
         } while (0)
-        if (a.tail) SGM2_SPLIT_LAUNCH(true); else SGM2_SPLIT_LAUNCH(false);
+        // a few pairs leave most SIMDs with a single wave: spread the three paths of a sweep over three wave groups
+        const bool pathWaves = batch <= path_waves_max_batch() && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+#define SGM2_SPLIT3_LAUNCH(TAILV)                                                                \
+        do {                                                                                     \
+            sgm2_hscan_kernel<TAILV, true, 16><<<gh, 256, 0, s>>>(a);                            \
+            sgm2_prepass_kernel<TAILV><<<gp, 256, 0, s2>>>(a);                                   \
+            if (aux) {                                                                           \
+                MD_HIP(hipEventRecord(aux->ev[1], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[1], 0));   \
+                MD_HIP(hipEventRecord(aux->ev[2], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[2], 0));   \
+            }                                                                                    \
+            sgm2_sweep3_kernel<false, TAILV><<<gs, 768, 0, s>>>(a);                              \
+            sgm2_sweep3_kernel<true, TAILV><<<gs, 768, 0, s2>>>(a);                              \
+            if (aux) { MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0)); }  \
+            sgm2_wta_sum_kernel<TAILV, true><<<dim3(pl.H, batch), 256, 0, s>>>(a);               \
+        } while (0)
+        if (pathWaves) { if (a.tail) SGM2_SPLIT3_LAUNCH(true); else SGM2_SPLIT3_LAUNCH(false); }
+        else if (a.tail) SGM2_SPLIT_LAUNCH(true); else SGM2_SPLIT_LAUNCH(false);
+#undef SGM2_SPLIT3_LAUNCH
 #undef SGM2_SPLIT_LAUNCH
         MD_HIP(hipGetLastError());
     } else if (l.mode == SGM2_SHEAR) {

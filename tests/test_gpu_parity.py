@@ -163,13 +163,17 @@ SGM_CASES = [
 
 
 # how a single pair is scheduled: "latency" = the default for small batches (two sweeps side by side on two
-# streams + summing winner-take-all), "pipeline" = the sheared strip pipeline that batches use, with the strip width of
-# small batches (512 lanes per workgroup) or of large ones (256)
-@pytest.fixture(params=["latency", "pipeline", "pipeline, narrow strips"])
+# streams + summing winner-take-all; for one pair the three paths of a sweep on three groups of waves, "latency, one
+# wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
+# with the strip width of small batches (512 lanes per workgroup) or of large ones (256)
+@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips"])
 def sgm_schedule(request, monkeypatch):
     monkeypatch.delenv("MDISP_SGM_SPLIT_MAX", raising=False)
     monkeypatch.delenv("MDISP_SGM_STRIP_LANES", raising=False)
-    if request.param != "latency":
+    monkeypatch.delenv("MDISP_SGM_PATH_WAVES_MAX", raising=False)
+    if request.param == "latency, one wave group":
+        monkeypatch.setenv("MDISP_SGM_PATH_WAVES_MAX", "0")
+    elif request.param != "latency":
         monkeypatch.setenv("MDISP_SGM_SPLIT_MAX", "0")
         monkeypatch.setenv("MDISP_SGM_STRIP_LANES", "256" if "narrow" in request.param else "512")
     return request.param
