@@ -114,6 +114,17 @@ __device__ __forceinline__ void load_cost_operands(const Sgm2Args& a, const u8* 
     // bytes at ascending addresses are descending disparities: byte j <-> e = 15 - j
     __builtin_memcpy(&rb, cRrow + x + a.maxD - a.minD - lic * DPL - 15, 16);
 }
+// The same with the left census byte fetched as its aligned dword (rows start 256-byte aligned): a byte that is
+// carried around a loop is kept as a byte by the compiler and re-extended right behind its load, which turns a request
+// issued several steps ahead into a wait on the spot.  The byte is extracted with census_byte() where it is consumed.
+__device__ __forceinline__ void load_cost_operands_w(const Sgm2Args& a, const u8* cLrow, const u8* cRrow, int x, int lic,
+                                                     u32& clw, uint4& rb)
+{
+    clw = *reinterpret_cast<const u32*>(cLrow + (x & ~3));
+    __builtin_memcpy(&rb, cRrow + x + a.maxD - a.minD - lic * DPL - 15, 16);
+}
+__device__ __forceinline__ u32 census_byte(u32 clw, int x) { return __builtin_amdgcn_ubfe(clw, 8 * (x & 3), 8); }
+
 __device__ __forceinline__ void cost_from_operands(u32 cl, const uint4& rb, u32 (&C)[NR])
 {
     const u32 m = cl * 0x01010101u;
@@ -336,54 +347,88 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
 
 // ---------------------------------------------------------------------------------------------
 // Diagonal pre-pass: run a path along its whole line and keep the state wherever it leaves a strip.
-// One lane-row per line, 16 lines per workgroup; W+H-1 lines per direction, directions in the
-// order (1,1) (-1,1) (1,-1) (-1,-1).
+// One lane-row per slot, 16 slots per workgroup, directions in the order (1,1) (-1,1) (1,-1) (-1,-1).
+// The W+H-1 lines of a direction have lengths 1, 2, .., m, m+1 (nd - 2m times), m, .., 1 with m = min(W,H) - 1;
+// a slot runs either one full-length line or a line of the rising ramp followed by the line of the falling ramp
+// that completes it to m + 1 steps, so every slot (and every workgroup) carries the same work.
+__host__ __device__ inline int prepass_slots(int H, int W) { return W + H - 1 - (min(W, H) - 1); }
+
+constexpr int PREPASS_PF = 4;
 template <bool TAIL, int CW = 16>
 __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
 {
     const int lic = threadIdx.x & 15, lr = threadIdx.x >> 4;
     const int pair = blockIdx.y;
     const int H = a.H, W = a.W;
-    const int nd = W + H - 1;
-    const int line = blockIdx.x * 16 + lr;
-    if (line >= 4 * nd) return;
-    const int q = line / nd, i = line - q * nd;
+    const int nd = W + H - 1, m = min(W, H) - 1, ns = nd - m;
+    const int slot = blockIdx.x * 16 + lr;
+    if (slot >= 4 * ns) return;
+    const int q = slot / ns, sl = slot - q * ns;
     const int dx = (q & 1) ? -1 : 1, dy = (q & 2) ? -1 : 1;
-    int x, y;
-    {
-        const int ys = dy > 0 ? 0 : H - 1;
-        if (i < W) { x = i; y = ys; }
-        else { const int j = i - W; y = dy > 0 ? 1 + j : H - 2 - j; x = dx > 0 ? 0 : W - 1; }
-    }
-    const int n = min(dx > 0 ? W - x : x + 1, dy > 0 ? H - y : y + 1);
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
     u16* bnd = a.bnd[q] + (size_t)pair * a.strideB;
     u32 tail[NR];
     make_tail(lic, a.D, tail);
+    const int full = nd - 2 * m;                          // lines of full length
+    // line c of the direction (1,1) is x - y = c - (H - 1); the other directions mirror x and / or y
+    auto line_start = [&](int c, int& x, int& y) {
+        const int e = c - (H - 1);
+        x = e >= 0 ? e : 0; y = e >= 0 ? 0 : -e;
+        if (dx < 0) x = W - 1 - x;
+        if (dy < 0) y = H - 1 - y;
+    };
+    const int T = m + 1;                                  // steps of every slot
+    const bool paired = sl >= full;
+    const int c1 = paired ? sl - full : m + sl;
+    const int n1 = paired ? c1 + 1 : T;                   // steps of the first line; the second one takes the rest
+    int x1, y1, x2, y2;
+    line_start(c1, x1, y1);
+    line_start(paired ? nd - m + c1 : c1, x2, y2);
+    // The loop is uniform (every lane runs T steps) and its loads are unconditional: a load or a loop exit under a
+    // per-lane condition makes the compiler wait for outstanding requests on the spot.
+    auto position = [&](int t, int& x, int& y) {
+        const bool second = t >= n1;
+        const int tt = second ? t - n1 : t;
+        x = (second ? x2 : x1) + tt * dx; y = (second ? y2 : y1) + tt * dy;
+    };
+    // every step of a diagonal touches another image row: operands are requested PREPASS_PF steps ahead
+    auto fetch = [&](int t, u32& clv, uint4& rbv) {
+        int xf, yf;
+        position(min(t, T - 1), xf, yf);
+        load_cost_operands_w(a, cLp + (size_t)yf * a.pL, cRp + (size_t)yf * a.pR, xf, lic, clv, rbv);
+    };
+    u32 cl[PREPASS_PF]; uint4 rb[PREPASS_PF];
+#pragma unroll
+    for (int u = 0; u < PREPASS_PF; u++) fetch(u, cl[u], rb[u]);
     u32 N[NR];
     zero8(N);
     if (TAIL) {
 #pragma unroll
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
     }
-    u32 cl; uint4 rb;
-    load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, cl, rb);
-    for (int t = 0; t < n; t++) {
-        u32 C[NR], L[NR];
-        cost_from_operands(cl, rb, C);
-        const int xn = x + dx, yn = y + dy;
-        if (t + 1 < n) load_cost_operands(a, cLp + (size_t)yn * a.pL, cRp + (size_t)yn * a.pR, xn, lic, cl, rb);
-        sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
-        // does the successor pixel open a new strip?  Then its workgroup will ask for this state,
-        // indexed by the successor's row and strip.
-        if (t + 1 < n) {
+    for (int t0 = 0; t0 < T; t0 += PREPASS_PF) {
+#pragma unroll
+        for (int u = 0; u < PREPASS_PF; u++) {
+            const int t = t0 + u;
+            if (t >= T) break;
+            int x, y;
+            position(t, x, y);
+            const bool restart = t == n1;                 // the second line starts from the image border
+#pragma unroll
+            for (int r = 0; r < NR; r++) N[r] = restart ? (TAIL ? tail[r] : 0u) : N[r];
+            u32 C[NR], L[NR];
+            cost_from_operands(census_byte(cl[u], x), rb[u], C);
+            fetch(t + PREPASS_PF, cl[u], rb[u]);
+            sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
+            // does the successor pixel open a new strip?  Then its workgroup will ask for this state,
+            // indexed by the successor's row and strip.
+            const int xn = x + dx, yn = y + dy;
             bool edge; int strip;
             if (dx > 0) { edge = (xn % CW) == 0; strip = xn / CW; }
             else { edge = (x % CW) == 0; strip = x / CW - 1; }
-            if (edge) store8(bnd + (((size_t)yn * a.nstrips + strip) * 256 + lic * DPL), N);
+            if (edge && t + 1 != n1 && t + 1 < T) store8(bnd + (((size_t)yn * a.nstrips + strip) * 256 + lic * DPL), N);
         }
-        x = xn; y = yn;
     }
 }
 
@@ -1178,7 +1223,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         // hscan || prepass, then down sweep || up sweep, then the summing winner-take-all
         a.S2 = (u16*)afterRec; a.splitUp = 1;
         hipStream_t s2 = aux ? aux->aux : s;
-        dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
+        dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * prepass_slots(pl.H, pl.W) + 15) / 16, batch), gs(a.nstrips, batch);
         if (aux) { MD_HIP(hipEventRecord(aux->ev[0], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[0], 0)); }
 #define SGM2_SPLIT_LAUNCH(TAILV)                                                                 \
         do {                                                                                     \
@@ -1232,7 +1277,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             else MD_TRY((launch_shear<16, 256>(s, pl, sa, batch, naturalOut)));
         }
     } else {
-    dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * (pl.W + pl.H - 1) + 15) / 16, batch), gs(a.nstrips, batch);
+    dim3 gh((2 * pl.H + 15) / 16, batch), gp((4 * prepass_slots(pl.H, pl.W) + 15) / 16, batch), gs(a.nstrips, batch);
 #define SGM2_LAUNCH(TAILV, U8V)                                          \
     do {                                                                 \
         sgm2_hscan_kernel<TAILV, U8V, 16><<<gh, 256, 0, s>>>(a);         \
