@@ -332,17 +332,30 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
 #pragma unroll
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
     }
-    u32 cl; uint4 rb;
-    load_cost_operands(a, cLrow, cRrow, x, lic, cl, rb);
-    for (int t = 0; t < W; t++) {
-        u32 C[NR], L[NR];
-        cost_from_operands(cl, rb, C);
-        if (t + 1 < W) load_cost_operands(a, cLrow, cRrow, x + dx, lic, cl, rb);
+    // One step = wait for this step's operands, store the previous step's values, request the next step's operands
+    // (unconditionally: past the end the last pixel is asked for again), compute.  The compiler drains all outstanding
+    // memory operations where the operands are first used; in this order the store it then waits for was issued a
+    // whole step earlier instead of a few instructions earlier.
+    u32 clw; uint4 rb;
+    load_cost_operands_w(a, cLrow, cRrow, x, lic, clw, rb);
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    u32 C[NR], L[NR];
+    auto compute = [&](int t) {
+        const int xn = t + 1 < W ? x + dx : x;
+        load_cost_operands_w(a, cLrow, cRrow, xn, lic, clw, rb);
         sgm_step<TAIL, LPC>(N, C, a.P1P1, a.P2P2, tail, L, lic);
-        if (U8) store16_stream(hrow + (size_t)x * DP, pack_bytes(L));
+        if (U8) pend = pack_bytes(L);
         else store8(reinterpret_cast<u16*>(hrow + (size_t)x * 2 * DP), L);
         x += dx;
+    };
+    cost_from_operands(census_byte(clw, x), rb, C);
+    compute(0);
+    for (int t = 1; t < W; t++) {
+        cost_from_operands(census_byte(clw, x), rb, C);
+        if (U8) store16_stream(hrow + (size_t)(x - dx) * DP, pend);
+        compute(t);
     }
+    if (U8) store16_stream(hrow + (size_t)(x - dx) * DP, pend);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -351,6 +364,16 @@ __global__ __launch_bounds__(256) void sgm2_hscan_kernel(Sgm2Args a)
 // The W+H-1 lines of a direction have lengths 1, 2, .., m, m+1 (nd - 2m times), m, .., 1 with m = min(W,H) - 1;
 // a slot runs either one full-length line or a line of the rising ramp followed by the line of the falling ramp
 // that completes it to m + 1 steps, so every slot (and every workgroup) carries the same work.
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(v);
+}
 __host__ __device__ inline int prepass_slots(int H, int W) { return W + H - 1 - (min(W, H) - 1); }
 
 constexpr int PREPASS_PF = 4;
@@ -386,40 +409,62 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
     line_start(c1, x1, y1);
     line_start(paired ? nd - m + c1 : c1, x2, y2);
     // The loop is uniform (every lane runs T steps) and its loads are unconditional: a load or a loop exit under a
-    // per-lane condition makes the compiler wait for outstanding requests on the spot.
-    auto position = [&](int t, int& x, int& y) {
-        const bool second = t >= n1;
-        const int tt = second ? t - n1 : t;
-        x = (second ? x2 : x1) + tt * dx; y = (second ? y2 : y1) + tt * dy;
+    // per-lane condition makes the compiler wait for outstanding requests on the spot.  Positions and request
+    // addresses advance incrementally; the jump to the second line is a per-lane select that only the steps inside the
+    // wave's window of line ends [nlo, nhi] execute.
+    const int nlo = wave_min_i32(n1), nhi = wave_max_i32(n1);
+    const ptrdiff_t dL = (ptrdiff_t)dy * (ptrdiff_t)a.pL + dx, dR = (ptrdiff_t)dy * (ptrdiff_t)a.pR + dx;
+    const int rofs = a.maxD - a.minD - lic * DPL - 15;
+    const u8* fL = cLp + (size_t)y1 * a.pL + x1;
+    const u8* fR = cRp + (size_t)y1 * a.pR + x1 + rofs;
+    const u8* const fL2 = cLp + (size_t)y2 * a.pL + x2;
+    const u8* const fR2 = cRp + (size_t)y2 * a.pR + x2 + rofs;
+    auto issue = [&](u32& clw, uint4& rbv) {
+        clw = *reinterpret_cast<const u32*>(fL - ((u32)reinterpret_cast<uintptr_t>(fL) & 3u));   // rows start 256-byte aligned
+        __builtin_memcpy(&rbv, fR, 16);
+    };
+    // move the request position to step tf (uniform); past the end it stays on the last pixel
+    auto advance_fetch = [&](int tf) {
+        if (tf < T) {
+            fL += dL; fR += dR;
+            if (tf >= nlo && tf <= nhi) {
+                const bool second = tf == n1;
+                fL = second ? fL2 : fL; fR = second ? fR2 : fR;
+            }
+        }
     };
     // every step of a diagonal touches another image row: operands are requested PREPASS_PF steps ahead
-    auto fetch = [&](int t, u32& clv, uint4& rbv) {
-        int xf, yf;
-        position(min(t, T - 1), xf, yf);
-        load_cost_operands_w(a, cLp + (size_t)yf * a.pL, cRp + (size_t)yf * a.pR, xf, lic, clv, rbv);
-    };
     u32 cl[PREPASS_PF]; uint4 rb[PREPASS_PF];
 #pragma unroll
-    for (int u = 0; u < PREPASS_PF; u++) fetch(u, cl[u], rb[u]);
+    for (int u = 0; u < PREPASS_PF; u++) {
+        if (u > 0) advance_fetch(u);
+        issue(cl[u], rb[u]);
+    }
     u32 N[NR];
     zero8(N);
     if (TAIL) {
 #pragma unroll
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
     }
+    int x = x1, y = y1;
     for (int t0 = 0; t0 < T; t0 += PREPASS_PF) {
 #pragma unroll
         for (int u = 0; u < PREPASS_PF; u++) {
             const int t = t0 + u;
             if (t >= T) break;
-            int x, y;
-            position(t, x, y);
-            const bool restart = t == n1;                 // the second line starts from the image border
+            if (t > 0) {
+                x += dx; y += dy;
+                if (t >= nlo && t <= nhi) {
+                    const bool second = t == n1;          // the second line starts from the image border
+                    x = second ? x2 : x; y = second ? y2 : y;
 #pragma unroll
-            for (int r = 0; r < NR; r++) N[r] = restart ? (TAIL ? tail[r] : 0u) : N[r];
+                    for (int r = 0; r < NR; r++) N[r] = second ? (TAIL ? tail[r] : 0u) : N[r];
+                }
+            }
             u32 C[NR], L[NR];
             cost_from_operands(census_byte(cl[u], x), rb[u], C);
-            fetch(t + PREPASS_PF, cl[u], rb[u]);
+            advance_fetch(t + PREPASS_PF);
+            issue(cl[u], rb[u]);
             sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
             // does the successor pixel open a new strip?  Then its workgroup will ask for this state,
             // indexed by the successor's row and strip.
