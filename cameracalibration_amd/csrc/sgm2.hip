@@ -660,7 +660,8 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
 {
     __shared__ u32 diag[2][2][CW][64];    // [row parity][diagonal][column]: normalised states, bytes
     __shared__ u32 part[2][2][CW][64];    // [row parity][diagonal][column]: path values, bytes
-    const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+    // the group is the same for every lane of a wave: kept in a scalar register so that branches on it are jumps
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), t = threadIdx.x & 255;
     const int lic = t & 15, lr = t >> 4;
     const int strip = blockIdx.x, pair = blockIdx.y;
     const int H = a.H, W = a.W;
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
     const int cw = min(CW, W - x0);
     const int x = x0 + lr;
     const bool colActive = lr < cw;
+    const int xl = min(x, W - 1);             // the idle columns of the last strip request and compute a valid pixel
     const u8* cLp = a.cL + (size_t)pair * a.strideL;
     const u8* cRp = a.cR + (size_t)pair * a.strideR;
     u8* Sp = reinterpret_cast<u8*>((UP ? a.S2 : a.S) + (size_t)pair * a.strideS);
@@ -675,9 +677,10 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
     // group 1: diagonal with dx = +1 (predecessor at x-1), group 2: dx = -1 (predecessor at x+1)
     const u16* bnd = a.bnd[(UP ? 2 : 0) + (grp == 2 ? 1 : 0)] + (size_t)pair * a.strideB;
     const int fam = grp == 2 ? 1 : 0;
-    const int nbCol = grp == 2 ? lr + 1 : lr - 1;
+    const int nbCol = min(max(grp == 2 ? lr + 1 : lr - 1, 0), CW - 1);
     const bool atBorder = grp == 2 ? x == W - 1 : x == 0;                                  // the path starts at this pixel
     const bool atEdge = !atBorder && (grp == 2 ? lr == cw - 1 : lr == 0);                   // predecessor in the next strip
+    const bool waveEdge = grp != 0 && __any(atEdge && colActive);                           // does this wave consume a border state?
     u32 tail[NR];
     make_tail(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
@@ -689,76 +692,91 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
 #pragma unroll
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
     }
-    // a row is a short chain now, so operands are requested PFD rows ahead
-    struct RowIn { u32 cl; uint4 rb, hb; u32 Bn[NR]; };
-    RowIn ring[PFD];
-    auto fetch_row = [&](int r, RowIn& in) {
-        const int y = ys + sy * r;
-        load_cost_operands(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, x, lic, in.cl, in.rb);
-        if (grp == 0) in.hb = *reinterpret_cast<const uint4*>(Hp + ((size_t)y * W + x) * 256 + lic * 16);
-        else if (r > 0 && atEdge) load8(bnd + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), in.Bn);
-    };
+    // A row is a short chain, so operands are requested PFD rows ahead.  The vertical group and the diagonal groups
+    // run separate copies of the row loop (same number of barriers in each): with the two kinds of request in one
+    // loop body the compiler waits for the cost operands before it issues the other group's load.  Every request sits
+    // under wave-uniform conditions only (a load under a per-lane condition is waited for right behind it), and the
+    // left census byte travels as its aligned dword (a byte carried around the loop is re-extended, i.e. waited for,
+    // behind its load).
+    if (grp == 0) {
+        struct RowIn { u32 clw; uint4 rb, hb; };
+        RowIn ring[PFD];
+        auto fetch_row = [&](int r, RowIn& in) {
+            const int y = ys + sy * r;
+            load_cost_operands_w(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, xl, lic, in.clw, in.rb);
+            in.hb = *reinterpret_cast<const uint4*>(Hp + ((size_t)y * W + xl) * 256 + lic * 16);
+        };
 #pragma unroll
-    for (int u = 0; u < PFD; u++) {
-        ring[u].cl = 0; ring[u].rb = make_uint4(0, 0, 0, 0); ring[u].hb = make_uint4(0, 0, 0, 0);
-        zero8(ring[u].Bn);
-        if (colActive && u < H) fetch_row(u, ring[u]);
-    }
-    uint4 pend = make_uint4(0, 0, 0, 0);      // group 0: horizontal + vertical bytes of the previous row
-    auto process_row = [&](int r, RowIn& in) {
-        const int y = ys + sy * r, par = r & 1;
-        if (colActive) {
-            u32 C[NR], L[NR], Bc[NR];
-            cost_from_operands(in.cl, in.rb, C);
-            const uint4 hcur = in.hb;
+        for (int u = 0; u < PFD; u++) fetch_row(min(u, H - 1), ring[u]);
+        uint4 pend = make_uint4(0, 0, 0, 0);      // horizontal + vertical bytes of the previous row
+        for (int r0 = 0; r0 < H; r0 += PFD) {
 #pragma unroll
-            for (int q = 0; q < NR; q++) Bc[q] = in.Bn[q];
-            if (r + PFD < H) fetch_row(r + PFD, in);
-            if (grp == 0) {
-                if (r > 0) {
+            for (int u = 0; u < PFD; u++) {
+                const int r = r0 + u;
+                if (r >= H) break;
+                RowIn& in = ring[u];
+                const int y = ys + sy * r, par = r & 1;
+                u32 C[NR], L[NR];
+                cost_from_operands(census_byte(in.clw, xl), in.rb, C);
+                const uint4 hcur = in.hb;
+                fetch_row(min(r + PFD, H - 1), in);
+                if (r > 0 && colActive) {
                     const uint4 pa = *reinterpret_cast<const uint4*>(&part[par ^ 1][0][lr][lic * 4]);
                     const uint4 pb = *reinterpret_cast<const uint4*>(&part[par ^ 1][1][lr][lic * 4]);
                     store16_stream(Sp + ((size_t)(y - sy) * W + x) * 256 + lic * 16, add4(pend, add4(pa, pb)));
                 }
                 sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
                 pend = add4(hcur, pack_bytes(L));
-            } else {
-                if (r == 0 || atBorder) {
-                    zero8(N);
-                    if (TAIL) {
-#pragma unroll
-                        for (int q = 0; q < NR; q++) N[q] |= tail[q];
-                    }
-                } else if (!atEdge) {
-                    unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][fam][nbCol][lic * 4]), N);
-                    if (TAIL) {   // the byte form drops the "infinite" marker of disparities >= D
-#pragma unroll
-                        for (int q = 0; q < NR; q++) N[q] |= tail[q];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < NR; q++) N[q] = Bc[q];
-                }
-                sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
-                *reinterpret_cast<uint4*>(&diag[par][fam][lr][lic * 4]) = pack_bytes(N);
-                *reinterpret_cast<uint4*>(&part[par][fam][lr][lic * 4]) = pack_bytes(L);
+                __syncthreads();   // part[par] complete before the next row reads it
             }
         }
-        __syncthreads();   // diag[par] and part[par] complete before the next row reads them
-    };
-    for (int r0 = 0; r0 < H; r0 += PFD) {
+        if (colActive) {
+            const int par = (H - 1) & 1, y = ys + sy * (H - 1);
+            const uint4 pa = *reinterpret_cast<const uint4*>(&part[par][0][lr][lic * 4]);
+            const uint4 pb = *reinterpret_cast<const uint4*>(&part[par][1][lr][lic * 4]);
+            store16_stream(Sp + ((size_t)y * W + x) * 256 + lic * 16, add4(pend, add4(pa, pb)));
+        }
+    } else {
+        struct RowIn { u32 clw; uint4 rb; u32 Bn[NR]; };
+        RowIn ring[PFD];
+        auto fetch_row = [&](int r, RowIn& in) {
+            const int y = ys + sy * r;
+            load_cost_operands_w(a, cLp + (size_t)y * a.pL, cRp + (size_t)y * a.pR, xl, lic, in.clw, in.rb);
+            if (waveEdge) load8(bnd + (((size_t)y * a.nstrips + strip) * 256 + lic * DPL), in.Bn);   // row 0's slot is never written nor used
+        };
 #pragma unroll
         for (int u = 0; u < PFD; u++) {
-            const int r = r0 + u;
-            if (r >= H) break;
-            process_row(r, ring[u]);
+            zero8(ring[u].Bn);
+            fetch_row(min(u, H - 1), ring[u]);
         }
-    }
-    if (colActive && grp == 0) {
-        const int par = (H - 1) & 1, y = ys + sy * (H - 1);
-        const uint4 pa = *reinterpret_cast<const uint4*>(&part[par][0][lr][lic * 4]);
-        const uint4 pb = *reinterpret_cast<const uint4*>(&part[par][1][lr][lic * 4]);
-        store16_stream(Sp + ((size_t)y * W + x) * 256 + lic * 16, add4(pend, add4(pa, pb)));
+        for (int r0 = 0; r0 < H; r0 += PFD) {
+#pragma unroll
+            for (int u = 0; u < PFD; u++) {
+                const int r = r0 + u;
+                if (r >= H) break;
+                RowIn& in = ring[u];
+                const int par = r & 1;
+                u32 C[NR], L[NR], Bc[NR], Nd[NR];
+                cost_from_operands(census_byte(in.clw, xl), in.rb, C);
+#pragma unroll
+                for (int q = 0; q < NR; q++) Bc[q] = in.Bn[q];
+                fetch_row(min(r + PFD, H - 1), in);
+                unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][fam][nbCol][lic * 4]), Nd);
+                const bool fresh = r == 0 || atBorder;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    // the byte form drops the "infinite" marker of disparities >= D
+                    const u32 fromLds = TAIL ? Nd[q] | tail[q] : Nd[q];
+                    N[q] = fresh ? (TAIL ? tail[q] : 0u) : atEdge ? Bc[q] : fromLds;
+                }
+                sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
+                if (colActive) {
+                    *reinterpret_cast<uint4*>(&diag[par][fam][lr][lic * 4]) = pack_bytes(N);
+                    *reinterpret_cast<uint4*>(&part[par][fam][lr][lic * 4]) = pack_bytes(L);
+                }
+                __syncthreads();   // diag[par] and part[par] complete before the next row reads them
+            }
+        }
     }
 }
 
