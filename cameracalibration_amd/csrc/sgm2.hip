@@ -1154,12 +1154,12 @@ enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2 };
 static int split_max_batch()
 {
     const char* e = getenv("MDISP_SGM_SPLIT_MAX");
-    return e ? atoi(e) : 3;      // from 4 pairs on the strip pipeline (512-lane strips) is faster
+    return e ? atoi(e) : 4;      // from 5 pairs on the strip pipeline (512-lane strips) is faster
 }
 static int path_waves_max_batch()
 {
     const char* e = getenv("MDISP_SGM_PATH_WAVES_MAX");
-    return e ? atoi(e) : 3;      // largest batch whose sweeps run one path per wave group (every batch of the latency schedule)
+    return e ? atoi(e) : 4;      // largest batch whose sweeps run one path per wave group (every batch of the latency schedule)
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
