@@ -156,6 +156,13 @@ template <> struct CVec<1> { typedef int16_t type; };
 template <> struct CVec<2> { typedef u32 type; };
 template <> struct CVec<4> { typedef uint2 type; };
 template <> struct CVec<8> { typedef uint4 type; };
+// ND accumulator values as one register block (what a vector load returns)
+struct alignas(16) bt_int8 { uint4 a, b; };
+template <class T, int ND> struct AccVec { typedef typename CVec<ND>::type type; };      // int16
+template <> struct AccVec<int, 1> { typedef int type; };
+template <> struct AccVec<int, 2> { typedef uint2 type; };
+template <> struct AccVec<int, 4> { typedef uint4 type; };
+template <> struct AccVec<int, 8> { typedef bt_int8 type; };
 
 struct PathArgs {
     const int16_t* C; void* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup;
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     const int16_t* __restrict__ Sin = a.S;
     int16_t* __restrict__ Sout = a.S;
     const int lane = threadIdx.x & 63;
-    int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the line is the same for every lane of a wave: kept in a scalar register, so that the loop bounds are uniform
+    int line = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (line >= nlines) return;
     if (MULTI) {
         int i = 0;
@@ -220,22 +228,24 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     typedef typename CVec<ND>::type V;
     // operands of step t + PF are requested when step t retires, so PF cost rows (and accumulator rows)
     // are in flight per wave while the serial recursion runs
+    // The requests are unconditional (lanes beyond D ask for the first lane's values, steps beyond the end for the
+    // last pixel again) and what they return stays packed until it is consumed: a load under a per-lane condition, or
+    // one whose result is widened for the ring, is waited for right behind the load, which would put a memory round trip
+    // into every step.
     constexpr int PF = ND <= 2 ? 16 : 8;
-    struct In { V c; V sOld; int old[ND]; };
+    typedef typename AccVec<AccT, ND>::type AV;
+    struct In { V c; V sOld; AV old; };
     In ring[PF];
+    const int kl = mine ? k0 : 0;
     auto fetch = [&](int t, In& in) {
-        if (!mine) return;
-        const size_t o = ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
+        const int tf = min(t, n - 1);
+        const size_t o = ((size_t)(y0 + tf * dy) * W + (x0 + tf * dx)) * D + kl;
         in.c = *reinterpret_cast<const V*>(a.C + o);
-        if (!FIRST) {
-#pragma unroll
-            for (int j = 0; j < ND; j++) in.old[j] = accp[o + j];
-        }
+        if (!FIRST) in.old = *reinterpret_cast<const AV*>(accp + o);
         if (LAST && !a.firstGroup) in.sOld = *reinterpret_cast<const V*>(Sin + o);
     };
 #pragma unroll
-    for (int u = 0; u < PF; u++)
-        if (u < n) fetch(u, ring[u]);
+    for (int u = 0; u < PF; u++) fetch(u, ring[u]);
     for (int t0 = 0; t0 < n; t0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; u++) {
@@ -244,8 +254,15 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         int16_t c[ND];
         int old[ND];
         __builtin_memcpy(c, &ring[u].c, sizeof(V));
+        if (FIRST) {
 #pragma unroll
-        for (int j = 0; j < ND; j++) old[j] = FIRST ? 0 : ring[u].old[j];
+            for (int j = 0; j < ND; j++) old[j] = 0;
+        } else {
+            AccT oldv[ND];
+            __builtin_memcpy(oldv, &ring[u].old, sizeof(AV));
+#pragma unroll
+            for (int j = 0; j < ND; j++) old[j] = (int)oldv[j];
+        }
         const int left = wave_shr1(Lp[ND - 1], 32767);
         const int right = wave_shl1(Lp[0], 32767);
         const int delta = minPrev + P2;
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
         for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
         minPrev = mn;
-        if (t + PF < n) fetch(t + PF, ring[u]);
+        fetch(t + PF, ring[u]);
     }
     }
 }

@@ -25,3 +25,11 @@ ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
 for _ in range(5):
     _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), H, W, 1, W, C.byref(p), out.data_ptr(), ws.data_ptr(), nb))
 torch.cuda.synchronize()
+# the context owns its stream when torch's current stream is the default one: time with the host clock around a synchronise
+import time
+_lib.check(lib.mdisp_synchronize(ctx.handle))
+t0 = time.perf_counter()
+for _ in range(10):
+    _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), H, W, 1, W, C.byref(p), out.data_ptr(), ws.data_ptr(), nb))
+_lib.check(lib.mdisp_synchronize(ctx.handle))
+print("%dx%d D=%d: %.3f ms per call" % (W, H, args[1], (time.perf_counter() - t0) * 100))
