@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void fgs_transpose_kernel(const float* src, in
 }
 
 // One lane per column of an n x m plane (n steps along the line, m lines): forward elimination, back substitution.
+constexpr int FGS_PF = 8;
 __global__ __launch_bounds__(64) void fgs_line_pass_kernel(float* u, const float* C, float* interD, int n, int m, float lambda)
 {
     const int j = blockIdx.x * 64 + threadIdx.x;
@@ -55,12 +56,37 @@ __global__ __launch_bounds__(64) void fgs_line_pass_kernel(float* u, const float
     float dprev = coef_cur / denom, uprev = u[j] / denom;
     interD[j] = dprev;
     u[j] = uprev;
-    float cNext = n > 1 ? C[(size_t)m + j] : 0.0f, uNext = n > 1 ? u[(size_t)m + j] : 0.0f;
-    for (int i = 1; i < n; i++) {
+    // Each line is a serial recurrence of a few operations per element, so a step must never wait for memory: the
+    // operands of FGS_PF elements ahead are in flight, requested unconditionally (past the end the last element is asked
+    // for again and dropped) so that the waits the compiler places cover only requests issued FGS_PF steps earlier.
+    float cq[FGS_PF], uq[FGS_PF];
+#pragma unroll
+    for (int k = 0; k < FGS_PF; k++) {
+        const size_t r = (size_t)min(1 + k, n - 1) * m + j;
+        cq[k] = C[r]; uq[k] = u[r];
+    }
+    // whole groups of FGS_PF steps run without an exit in the middle (an early exit makes the compiler rotate the ring
+    // through copies, which wait for the requests just issued); the last few steps load directly
+    int i = 1;
+    for (; i + FGS_PF <= n; i += FGS_PF) {
+#pragma unroll
+        for (int k = 0; k < FGS_PF; k++) {
+            const float coef_prev = coef_cur;
+            coef_cur = lambda * cq[k];
+            const float ui = uq[k];
+            const size_t r = (size_t)min(i + k + FGS_PF, n - 1) * m + j;
+            cq[k] = C[r]; uq[k] = u[r];
+            denom = (1.0f - coef_prev - coef_cur) - dprev * coef_prev;
+            dprev = coef_cur / denom;
+            uprev = (ui - uprev * coef_prev) / denom;
+            interD[(size_t)(i + k) * m + j] = dprev;
+            u[(size_t)(i + k) * m + j] = uprev;
+        }
+    }
+    for (; i < n; i++) {
         const float coef_prev = coef_cur;
-        coef_cur = lambda * cNext;
-        const float ui = uNext;
-        if (i + 1 < n) { cNext = C[(size_t)(i + 1) * m + j]; uNext = u[(size_t)(i + 1) * m + j]; }   // next row in flight
+        coef_cur = lambda * C[(size_t)i * m + j];
+        const float ui = u[(size_t)i * m + j];
         denom = (1.0f - coef_prev - coef_cur) - dprev * coef_prev;
         dprev = coef_cur / denom;
         uprev = (ui - uprev * coef_prev) / denom;
@@ -68,7 +94,23 @@ __global__ __launch_bounds__(64) void fgs_line_pass_kernel(float* u, const float
         u[(size_t)i * m + j] = uprev;
     }
     float unext = uprev;
-    for (int i = n - 2; i >= 0; i--) {
+    float dq[FGS_PF];
+#pragma unroll
+    for (int k = 0; k < FGS_PF; k++) {
+        const size_t r = (size_t)max(n - 2 - k, 0) * m + j;
+        uq[k] = u[r]; dq[k] = interD[r];
+    }
+    i = n - 2;
+    for (; i - (FGS_PF - 1) >= 0; i -= FGS_PF) {
+#pragma unroll
+        for (int k = 0; k < FGS_PF; k++) {
+            unext = uq[k] - dq[k] * unext;
+            const size_t r = (size_t)max(i - k - FGS_PF, 0) * m + j;
+            uq[k] = u[r]; dq[k] = interD[r];
+            u[(size_t)(i - k) * m + j] = unext;
+        }
+    }
+    for (; i >= 0; i--) {
         unext = u[(size_t)i * m + j] - interD[(size_t)i * m + j] * unext;
         u[(size_t)i * m + j] = unext;
     }
