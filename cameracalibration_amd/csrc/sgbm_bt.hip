@@ -246,20 +246,16 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     };
 #pragma unroll
     for (int u = 0; u < PF; u++) fetch(u, ring[u]);
-    for (int t0 = 0; t0 < n; t0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-        const int t = t0 + u;
-        if (t >= n) break;
+    auto step = [&](int t, const In& in) {
         int16_t c[ND];
         int old[ND];
-        __builtin_memcpy(c, &ring[u].c, sizeof(V));
+        __builtin_memcpy(c, &in.c, sizeof(V));
         if (FIRST) {
 #pragma unroll
             for (int j = 0; j < ND; j++) old[j] = 0;
         } else {
             AccT oldv[ND];
-            __builtin_memcpy(oldv, &ring[u].old, sizeof(AV));
+            __builtin_memcpy(oldv, &in.old, sizeof(AV));
 #pragma unroll
             for (int j = 0; j < ND; j++) old[j] = (int)oldv[j];
         }
@@ -281,7 +277,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
             const size_t o = ((size_t)(y0 + t * dy) * W + (x0 + t * dx)) * D + k0;
             if (LAST) {
                 int16_t sv[ND];
-                if (!a.firstGroup) __builtin_memcpy(sv, &ring[u].sOld, sizeof(V));
+                if (!a.firstGroup) __builtin_memcpy(sv, &in.sOld, sizeof(V));
 #pragma unroll
                 for (int j = 0; j < ND; j++) {
                     const int v = (a.firstGroup ? 0 : (int)sv[j]) + old[j] + Ln[j];
@@ -303,9 +299,21 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
         for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
         minPrev = mn;
-        fetch(t + PF, ring[u]);
+    };
+    // whole groups of PF steps run without an exit in the middle (an early exit makes the compiler rotate the ring through
+    // copies, which wait for the requests just issued); the last steps of a line use what the ring already holds
+    int t = 0;
+    for (; t + PF <= n; t += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const In cur = ring[u];
+            fetch(t + u + PF, ring[u]);
+            step(t + u, cur);
+        }
     }
-    }
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        if (t + u < n) step(t + u, ring[u]);
 }
 
 // S = saturate_cast<short>(S + acc)   (first group: S starts at zero)
