@@ -447,11 +447,8 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
         for (int r = 0; r < NR; r++) N[r] |= tail[r];
     }
     int x = x1, y = y1;
-    for (int t0 = 0; t0 < T; t0 += PREPASS_PF) {
-#pragma unroll
-        for (int u = 0; u < PREPASS_PF; u++) {
-            const int t = t0 + u;
-            if (t >= T) break;
+    // whole groups of PREPASS_PF steps run without an exit in the middle; the last steps use what the ring holds
+    auto step = [&](int t, u32& clw, uint4& rbv, bool more) {
             if (t > 0) {
                 x += dx; y += dy;
                 if (t >= nlo && t <= nhi) {
@@ -462,9 +459,11 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
                 }
             }
             u32 C[NR], L[NR];
-            cost_from_operands(census_byte(cl[u], x), rb[u], C);
-            advance_fetch(t + PREPASS_PF);
-            issue(cl[u], rb[u]);
+            cost_from_operands(census_byte(clw, x), rbv, C);
+            if (more) {
+                advance_fetch(t + PREPASS_PF);
+                issue(clw, rbv);
+            }
             sgm_step<TAIL>(N, C, a.P1P1, a.P2P2, tail, L);
             // does the successor pixel open a new strip?  Then its workgroup will ask for this state,
             // indexed by the successor's row and strip.
@@ -473,8 +472,15 @@ __global__ __launch_bounds__(256) void sgm2_prepass_kernel(Sgm2Args a)
             if (dx > 0) { edge = (xn % CW) == 0; strip = xn / CW; }
             else { edge = (x % CW) == 0; strip = x / CW - 1; }
             if (edge && t + 1 != n1 && t + 1 < T) store8(bnd + (((size_t)yn * a.nstrips + strip) * 256 + lic * DPL), N);
-        }
+    };
+    int t = 0;
+    for (; t + PREPASS_PF <= T; t += PREPASS_PF) {
+#pragma unroll
+        for (int u = 0; u < PREPASS_PF; u++) step(t + u, cl[u], rb[u], true);
     }
+#pragma unroll
+    for (int u = 0; u < PREPASS_PF; u++)
+        if (t + u < T) step(t + u, cl[u], rb[u], false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -709,17 +715,14 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
 #pragma unroll
         for (int u = 0; u < PFD; u++) fetch_row(min(u, H - 1), ring[u]);
         uint4 pend = make_uint4(0, 0, 0, 0);      // horizontal + vertical bytes of the previous row
-        for (int r0 = 0; r0 < H; r0 += PFD) {
-#pragma unroll
-            for (int u = 0; u < PFD; u++) {
-                const int r = r0 + u;
-                if (r >= H) break;
-                RowIn& in = ring[u];
+        // whole groups of PFD rows run without an exit in the middle (an early exit makes the compiler rotate the ring
+        // through copies, which wait for the requests just issued); the last rows use what the ring already holds
+        auto row = [&](int r, RowIn& in, bool more) {
                 const int y = ys + sy * r, par = r & 1;
                 u32 C[NR], L[NR];
                 cost_from_operands(census_byte(in.clw, xl), in.rb, C);
                 const uint4 hcur = in.hb;
-                fetch_row(min(r + PFD, H - 1), in);
+                if (more) fetch_row(min(r + PFD, H - 1), in);
                 if (r > 0 && colActive) {
                     const uint4 pa = *reinterpret_cast<const uint4*>(&part[par ^ 1][0][lr][lic * 4]);
                     const uint4 pb = *reinterpret_cast<const uint4*>(&part[par ^ 1][1][lr][lic * 4]);
@@ -728,8 +731,15 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
                 sgm_step<TAIL>(N, C, P1P1, P2P2, tail, L);
                 pend = add4(hcur, pack_bytes(L));
                 __syncthreads();   // part[par] complete before the next row reads it
-            }
+        };
+        int r = 0;
+        for (; r + PFD <= H; r += PFD) {
+#pragma unroll
+            for (int u = 0; u < PFD; u++) row(r + u, ring[u], true);
         }
+#pragma unroll
+        for (int u = 0; u < PFD; u++)
+            if (r + u < H) row(r + u, ring[u], false);
         if (colActive) {
             const int par = (H - 1) & 1, y = ys + sy * (H - 1);
             const uint4 pa = *reinterpret_cast<const uint4*>(&part[par][0][lr][lic * 4]);
@@ -749,18 +759,13 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
             zero8(ring[u].Bn);
             fetch_row(min(u, H - 1), ring[u]);
         }
-        for (int r0 = 0; r0 < H; r0 += PFD) {
-#pragma unroll
-            for (int u = 0; u < PFD; u++) {
-                const int r = r0 + u;
-                if (r >= H) break;
-                RowIn& in = ring[u];
+        auto row = [&](int r, RowIn& in, bool more) {
                 const int par = r & 1;
                 u32 C[NR], L[NR], Bc[NR], Nd[NR];
                 cost_from_operands(census_byte(in.clw, xl), in.rb, C);
 #pragma unroll
                 for (int q = 0; q < NR; q++) Bc[q] = in.Bn[q];
-                fetch_row(min(r + PFD, H - 1), in);
+                if (more) fetch_row(min(r + PFD, H - 1), in);
                 unpack_bytes(*reinterpret_cast<const uint4*>(&diag[par ^ 1][fam][nbCol][lic * 4]), Nd);
                 const bool fresh = r == 0 || atBorder;
 #pragma unroll
@@ -775,8 +780,15 @@ __global__ __launch_bounds__(768) void sgm2_sweep3_kernel(Sgm2Args a)
                     *reinterpret_cast<uint4*>(&part[par][fam][lr][lic * 4]) = pack_bytes(L);
                 }
                 __syncthreads();   // diag[par] and part[par] complete before the next row reads them
-            }
+        };
+        int r = 0;
+        for (; r + PFD <= H; r += PFD) {
+#pragma unroll
+            for (int u = 0; u < PFD; u++) row(r + u, ring[u], true);
         }
+#pragma unroll
+        for (int u = 0; u < PFD; u++)
+            if (r + u < H) row(r + u, ring[u], false);
     }
 }
 
