@@ -52,6 +52,18 @@ __device__ __forceinline__ int bt_one(const u8* __restrict__ a, const u8* __rest
     return min(c0, c1);
 }
 
+// the same on rows whose edge pixels are repeated once on either side
+__device__ __forceinline__ int bt_one_padded(const u8* a, const u8* b, int x, int x2)
+{
+    const int u = a[x], ul = (u + a[x - 1]) / 2, ur = (u + a[x + 1]) / 2;
+    const int u0 = min(min(ul, ur), u), u1 = max(max(ul, ur), u);
+    const int v = b[x2], vl = (v + b[x2 - 1]) / 2, vr = (v + b[x2 + 1]) / 2;
+    const int v0 = min(min(vl, vr), v), v1 = max(max(vl, vr), v);
+    const int c0 = max(max(0, u - v1), v0 - u);
+    const int c1 = max(max(0, v - u1), u0 - v);
+    return min(c0, c1);
+}
+
 // pixel cost of the computed columns x in [minX1, W): pix[y][x1][k], disparity minD + k; the raw
 // planes count a quarter
 __global__ __launch_bounds__(256) void bt_cost_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
@@ -99,12 +111,15 @@ __global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restric
 __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
                                                            int16_t* __restrict__ out)
 {
-    extern __shared__ u8 planeRows[];                    // [2 * np][W]: left planes, then right planes
-    const int np = 2 * g.cn, W = g.W, y = blockIdx.y;
-    for (int i = threadIdx.x; i < np * W; i += 256) {
-        const int c = i / W, x = i - c * W;
+    // [2 * np][W + 2]: left planes, then right planes, every row with its edge pixels repeated once on either side:
+    // the interpolated neighbours (u + u(x-1)) / 2 and (u + u(x+1)) / 2 of an edge pixel are then the pixel itself, as the
+    // library defines them, and every read is unconditional (a read under a per-lane condition is waited for alone)
+    extern __shared__ u8 planeRows[];
+    const int np = 2 * g.cn, W = g.W, WP = W + 2, y = blockIdx.y;
+    for (int i = threadIdx.x; i < np * WP; i += 256) {
+        const int c = i / WP, x = min(max(i - c * WP - 1, 0), W - 1);
         planeRows[i] = p1[(size_t)c * g.N + (size_t)y * W + x];
-        planeRows[np * W + i] = p2[(size_t)c * g.N + (size_t)y * W + x];
+        planeRows[np * WP + i] = p2[(size_t)c * g.N + (size_t)y * W + x];
     }
     __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
     auto pix = [&](int x1) -> int {
         const int x = x1 + g.minX1, x2 = x - (g.minD + k);
         int cost = 0;
-        for (int c = 0; c < np; c++) cost += bt_one(planeRows + c * W, planeRows + (np + c) * W, W, x, x2) >> (c < g.cn ? 0 : 2);
+        for (int c = 0; c < np; c++) cost += bt_one_padded(planeRows + c * WP + 1, planeRows + (np + c) * WP + 1, x, x2) >> (c < g.cn ? 0 : 2);
         return cost;
     };
     // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window
@@ -598,7 +613,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
-    const size_t rowLds = (size_t)4 * cn * W;
+    const size_t rowLds = (size_t)4 * cn * (W + 2);
     if (rowLds <= 60 * 1024) {
         bt_cost_hsum_kernel<<<dim3((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG), 256, rowLds, s>>>(pl1, pl2, g, v1);
         bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
