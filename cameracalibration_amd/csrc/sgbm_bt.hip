@@ -145,19 +145,41 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
 
 // Vertical window sum as a running sum down the image (window clamped to the image rows); the first computed
 // column keeps the block cost of row 0 in every row.  Same values as bt_window_kernel<true>.
+// A lane owns four neighbouring elements of a row (D is a multiple of 16, so the row length is a multiple of four and the
+// four share their column): 8-byte loads and stores.
 __global__ __launch_bounds__(256) void bt_vsum_kernel(const int16_t* __restrict__ in, BtGeom g, int16_t* __restrict__ out)
 {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, rowN = (size_t)g.W1 * g.D;
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, rowN = (size_t)g.W1 * g.D;
     if (e >= rowN) return;
     const int h = g.bs / 2, H = g.H;
     const bool frozen = e < (size_t)g.D;                 // x1 == 0: row 0's sum everywhere
     const int ya = blockIdx.y * BT_VBAND, yb = min(ya + BT_VBAND, H), yc = frozen ? 0 : ya;
-    int s = 0;
-    for (int i = -h; i <= h; i++) s += in[(size_t)min(max(yc + i, 0), H - 1) * rowN + e];
-    out[(size_t)ya * rowN + e] = (int16_t)s;
+    auto load4 = [&](int y, int (&v)[4]) {
+        const uint2 w = *reinterpret_cast<const uint2*>(in + (size_t)y * rowN + e);
+        v[0] = (int16_t)(w.x & 0xFFFFu); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFFu); v[3] = (int16_t)(w.y >> 16);
+    };
+    auto store4 = [&](int y, const int (&v)[4]) {
+        uint2 w;
+        w.x = ((u32)v[0] & 0xFFFFu) | ((u32)v[1] << 16); w.y = ((u32)v[2] & 0xFFFFu) | ((u32)v[3] << 16);
+        *reinterpret_cast<uint2*>(out + (size_t)y * rowN + e) = w;
+    };
+    int s[4] = {0, 0, 0, 0};
+    for (int i = -h; i <= h; i++) {
+        int v[4];
+        load4(min(max(yc + i, 0), H - 1), v);
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[q] += v[q];
+    }
+    store4(ya, s);
+    // unconditional loads (the frozen column drops the difference), several rows in flight
+#pragma unroll 4
     for (int y = ya + 1; y < yb; y++) {
-        if (!frozen) s += (int)in[(size_t)min(y + h, H - 1) * rowN + e] - (int)in[(size_t)max(y - h - 1, 0) * rowN + e];
-        out[(size_t)y * rowN + e] = (int16_t)s;
+        int a[4], b[4];
+        load4(min(y + h, H - 1), a);
+        load4(max(y - h - 1, 0), b);
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[q] += frozen ? 0 : a[q] - b[q];
+        store4(y, s);
     }
 }
 
@@ -616,7 +638,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     const size_t rowLds = (size_t)4 * cn * (W + 2);
     if (rowLds <= 60 * 1024) {
         bt_cost_hsum_kernel<<<dim3((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG), 256, rowLds, s>>>(pl1, pl2, g, v1);
-        bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
+        bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D / 4), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
     } else {
         bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
         bt_window_kernel<false><<<gv, 256, 0, s>>>(v0, g, v1);
