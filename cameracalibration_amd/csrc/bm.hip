@@ -128,18 +128,21 @@ __global__ void bm_vsum_wta_kernel(const u16* hs, BmGeom g, BmSelect sel, int16_
     const int w = g.w, ndisp = g.ndisp;
     const int yv0 = blockIdx.y * BM_BAND, yv1 = min(yv0 + BM_BAND, g.Hv);
     const size_t rowStride = (size_t)(ndisp + 1) * g.Wv;
-    const u16* col = hs + xvc;
+    // a row's base is uniform and the element offsets are 32-bit (one row of window sums is far below 2^31 elements):
+    // no 64-bit address per candidate is kept in registers
+    auto rowbase = [&](int y) { return hs + (size_t)y * rowStride; };
+    auto cand_off = [&](int i) { return (unsigned)(min(d0 + i, ndisp - 1) * g.Wv + xvc); };
+    // Every load below is unconditional (candidates beyond ndisp repeat the last one and are never looked at): a load under
+    // its own condition is waited for alone, one memory round trip per candidate and row.
     int sums[BM_DPT], tsum = 0;
 #pragma unroll
     for (int i = 0; i < BM_DPT; i++) sums[i] = 0;
     // window of the band's first row: image rows [ymin + yv0 - w, ymin + yv0 + w]
     const int yTop = g.ymin + yv0 - w;
     for (int j = 0; j <= 2 * w; j++) {
-        const u16* row = col + (size_t)(yTop + j) * rowStride;
 #pragma unroll
-        for (int i = 0; i < BM_DPT; i++)
-            if (d0 + i < ndisp) sums[i] += row[(size_t)(d0 + i) * g.Wv];
-        tsum += row[(size_t)ndisp * g.Wv];
+        for (int i = 0; i < BM_DPT; i++) sums[i] += rowbase(yTop + j)[cand_off(i)];
+        tsum += rowbase(yTop + j)[(unsigned)(ndisp * g.Wv + xvc)];
     }
     for (int yv = yv0; yv < yv1; yv++) {
         const int par = yv & 1;
@@ -188,12 +191,15 @@ __global__ void bm_vsum_wta_kernel(const u16* hs, BmGeom g, BmSelect sel, int16_
         }
         // slide the window one row down
         if (yv + 1 < yv1) {
-            const u16* add = col + (size_t)(Y + w + 1) * rowStride;
-            const u16* sub = col + (size_t)(Y - w) * rowStride;
+            const u16* add = rowbase(Y + w + 1);
+            const u16* sub = rowbase(Y - w);
+            int va[BM_DPT], vs[BM_DPT];
 #pragma unroll
-            for (int i = 0; i < BM_DPT; i++)
-                if (d0 + i < ndisp) sums[i] += (int)add[(size_t)(d0 + i) * g.Wv] - (int)sub[(size_t)(d0 + i) * g.Wv];
-            tsum += (int)add[(size_t)ndisp * g.Wv] - (int)sub[(size_t)ndisp * g.Wv];
+            for (int i = 0; i < BM_DPT; i++) { va[i] = add[cand_off(i)]; vs[i] = sub[cand_off(i)]; }
+            const unsigned ot = (unsigned)(ndisp * g.Wv + xvc);
+            tsum += (int)add[ot] - (int)sub[ot];
+#pragma unroll
+            for (int i = 0; i < BM_DPT; i++) sums[i] += va[i] - vs[i];
         }
     }
 }
