@@ -131,14 +131,30 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
         for (int c = 0; c < np; c++) cost += bt_one_padded(planeRows + c * WP + 1, planeRows + (np + c) * WP + 1, x, x2) >> (c < g.cn ? 0 : 2);
         return cost;
     };
-    // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window
+    // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window.
+    // Every pixel cost is evaluated once: a lane keeps the costs of the window's columns in its own ring of bs + 1
+    // slots in LDS ([slot][lane], conflict-free), so the column that leaves the window is read back, not recomputed.
+    int16_t* ring = reinterpret_cast<int16_t*>(planeRows + ((2 * np * WP + 3) & ~3)) + threadIdx.x;
+    const int R = g.bs + 1;
     const int xa = blockIdx.z * BT_SEG, xb = min(xa + BT_SEG, W1);
+    int slotLeave = (xa - h) % R;
+    if (slotLeave < 0) slotLeave += R;
+    int slotEnter = slotLeave;
     int s = 0;
-    for (int i = -h; i <= h; i++) s += pix(min(max(xa + i, 0), W1 - 1));
+    for (int i = -h; i <= h; i++) {
+        const int v = pix(min(max(xa + i, 0), W1 - 1));
+        s += v;
+        ring[slotEnter * 256] = (int16_t)v;
+        slotEnter = slotEnter + 1 == R ? 0 : slotEnter + 1;
+    }
     int16_t* o = out + (size_t)y * W1 * g.D + k;
     o[(size_t)xa * g.D] = (int16_t)s;
     for (int x1 = xa + 1; x1 < xb; x1++) {
-        s += pix(min(x1 + h, W1 - 1)) - pix(max(x1 - h - 1, 0));
+        const int enter = pix(min(x1 + h, W1 - 1));
+        s += enter - (int)ring[slotLeave * 256];
+        ring[slotEnter * 256] = (int16_t)enter;
+        slotEnter = slotEnter + 1 == R ? 0 : slotEnter + 1;
+        slotLeave = slotLeave + 1 == R ? 0 : slotLeave + 1;
         o[(size_t)x1 * g.D] = (int16_t)s;
     }
 }
@@ -635,7 +651,8 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
-    const size_t rowLds = (size_t)4 * cn * (W + 2);
+    // plane rows + the per-lane ring of pixel costs (bs + 1 slots of 256 int16)
+    const size_t rowLds = (((size_t)4 * cn * (W + 2) + 3) & ~(size_t)3) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
     if (rowLds <= 60 * 1024) {
         bt_cost_hsum_kernel<<<dim3((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG), 256, rowLds, s>>>(pl1, pl2, g, v1);
         bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D / 4), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
