@@ -646,10 +646,11 @@ struct StoreOut {
     __device__ void operator()(int x, int y, int k, double s0, double s1) const
     {
         const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
+        const float gv = G[i];                   // requested together with the divisor: one memory round trip, not two
         float ab, bb;
         if (div) { const double d = div[i]; ab = (float)(s0 * 1.0 / d); bb = (float)(s1 * 1.0 / d); }
         else { ab = (float)(s0 * scale); bb = (float)(s1 * scale); }
-        V[o] = __fadd_rn(__fmul_rn(ab, G[i]), bb);
+        V[o] = __fadd_rn(__fmul_rn(ab, gv), bb);
         if (beta) beta[o] = __fdiv_rn(ab, __fsub_rn(1.0f, ab));
     }
 };
