@@ -10,6 +10,8 @@
 #include <opencv2/imgproc.hpp>   // resize(INTER_AREA) of getRectifiedImages stays on the host
 
 #include <algorithm>
+#include <cmath>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -135,8 +137,6 @@ inline void getRectifiedImages(cv::Mat imgLeft, cv::Mat imgRight, std::string ca
     rectifiedRight = out[1](v).clone();
 }
 
-#endif  // MDISP_CV_HPP
-
 // methods/method_StereoMatching.h:94-112 (namespace stereomatch_1): the fixed-window matchers on cv::Mat
 namespace stereomatch_1 {
 inline cv::Mat computeAD(cv::Mat l, cv::Mat r, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeAD(l, r, minDisparity, numDisparity); }
@@ -152,3 +152,5 @@ inline cv::Mat computeSSD(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparit
 inline cv::Mat computeSSD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_inteOpti(l, r, winSize, minDisparity, numDisparity); }
 inline cv::Mat computeSSD_BFOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_BFOpti(l, r, winSize, minDisparity, numDisparity); }
 }  // namespace stereomatch_1
+
+#endif  // MDISP_CV_HPP
