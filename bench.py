@@ -111,8 +111,10 @@ def main():
 
     from cameracalibration_amd import _lib, api, shard
     lib = _lib.load()
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(device=local_rank, stream=stream)
+    # a stream of torch's own (not the legacy default stream), handed to the library: the inputs below are complete
+    # before the first call because the uploads are followed by a device-wide synchronisation
+    tstream = torch.cuda.Stream()
+    ctx = _lib.Context(device=local_rank, stream=tstream.cuda_stream)
     params = api.sgbm_params(0, D, P1, P2, 10, 1, args.paths, 1)
 
     # synthetic inputs, resident in HBM before the timed region
@@ -148,6 +150,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ctx.synchronize()           # also reads the pipeline's sticky error word: a hand-off timeout fails the run
     elapsed = shard.slowest_rank_seconds(elapsed, dist if world > 1 else None,
                                          device="cuda" if args.backend == "nccl" else "cpu")
 

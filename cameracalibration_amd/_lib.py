@@ -16,6 +16,9 @@ _DEPTH_OF = {np.dtype(np.uint8): MDISP_8U, np.dtype(np.int8): MDISP_8S, np.dtype
              np.dtype(np.float64): MDISP_64F}
 
 E_BADARG, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_RANGE, E_NOMEM = -1, -2, -3, -4, -5, -6
+# keys of mdisp_tuning_set (include/mdisp.h)
+(TUNE_SGM_SPLIT_MAX, TUNE_SGM_PATH_WAVES_MAX, TUNE_SGM_STRIP_LANES, TUNE_SGM_FORCE_PREPASS, TUNE_SGM_LANES16,
+ TUNE_SGM_PER_DIRECTION, TUNE_SGBM_BT_SEQUENTIAL, TUNE_SGM_PIPELINE, TUNE_SGM_PLANT_ERROR, TUNE_COUNT) = range(10)
 
 
 class mdisp_image(C.Structure):
@@ -56,6 +59,7 @@ EXPORTS = [
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
+    "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
 ]
 
@@ -78,6 +82,9 @@ def load():
     lib.mdisp_last_error.restype = C.c_char_p
     lib.mdisp_device_count.restype = C.c_int
     lib.mdisp_create.argtypes = [P(vp), C.c_int, vp]
+    lib.mdisp_create_on_stream.argtypes = [P(vp), C.c_int, vp]
+    lib.mdisp_tuning_set.argtypes = [C.c_int, C.c_int]
+    lib.mdisp_tuning_get.argtypes = [C.c_int]
     lib.mdisp_destroy.argtypes = [vp]
     lib.mdisp_destroy.restype = None
     lib.mdisp_synchronize.argtypes = [vp]
@@ -171,8 +178,13 @@ class Context:
     """Owns one mdisp_ctx (one HIP stream + workspace)."""
 
     def __init__(self, device=-1, stream=None):
+        """stream=None: the context creates its own stream; an integer (0 = the legacy default stream included):
+        the hipStream_t to enqueue on."""
         self._h = C.c_void_p()
-        check(load().mdisp_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None))
+        if stream is None:
+            check(load().mdisp_create(C.byref(self._h), device, None))
+        else:
+            check(load().mdisp_create_on_stream(C.byref(self._h), device, C.c_void_p(stream)))
 
     @property
     def handle(self):
@@ -191,6 +203,15 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def tuning_set(key, value):
+    check(load().mdisp_tuning_set(key, value))
+
+
+def tuning_reset():
+    for k in range(TUNE_COUNT):
+        check(load().mdisp_tuning_set(k, -1))
 
 
 _default_ctx = None

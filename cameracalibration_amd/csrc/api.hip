@@ -16,6 +16,17 @@ void mdisp_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* mdisp_last_error(void) { return g_err; }
+
+static int g_tune[MDISP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+int md_tune(int key) { return key >= 0 && key < MDISP_TUNE_COUNT ? g_tune[key] : -1; }
+void md_tune_clear(int key) { if (key >= 0 && key < MDISP_TUNE_COUNT) g_tune[key] = -1; }
+extern "C" int mdisp_tuning_set(int key, int value)
+{
+    MD_REQUIRE(key >= 0 && key < MDISP_TUNE_COUNT, MDISP_E_BADARG, "unknown tuning key %d", key);
+    g_tune[key] = value < 0 ? -1 : value;
+    return MDISP_OK;
+}
+extern "C" int mdisp_tuning_get(int key) { return md_tune(key); }
 extern "C" int mdisp_version(void) { return 100; }
 
 extern "C" int mdisp_device_count(void)
@@ -25,7 +36,7 @@ extern "C" int mdisp_device_count(void)
     return n;
 }
 
-extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
+static int create_ctx(mdisp_ctx** out, int device, void* stream, bool useGiven)
 {
     MD_REQUIRE(out, MDISP_E_BADARG, "null context pointer");
     *out = nullptr;
@@ -39,9 +50,9 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_failed = false; c->aux = nullptr; c->aux_ready = false; c->stage = nullptr; c->stage_bytes = 0;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_pending = false; c->aux = nullptr; c->aux_ready = false; c->stage = nullptr; c->stage_bytes = 0;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    if (useGiven) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
             delete c; mdisp_set_error("hipStreamCreate failed"); return MDISP_E_HIP;
@@ -50,9 +61,16 @@ extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream)
     }
     for (int i = 0; i < 6; i++)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { mdisp_set_error("hipEventCreate failed"); delete c; return MDISP_E_HIP; }
+    // the sticky hand-off error word of the pipelined SGM kernels (one 256-byte line of its own)
+    if (hipMalloc((void**)&c->sgm_err, 256) != hipSuccess || hipMemset(c->sgm_err, 0, 256) != hipSuccess) {
+        mdisp_set_error("hipMalloc of the context's status word failed"); delete c; return MDISP_E_NOMEM;
+    }
     *out = c;
     return MDISP_OK;
 }
+
+extern "C" int mdisp_create(mdisp_ctx** out, int device, void* stream) { return create_ctx(out, device, stream, stream != nullptr); }
+extern "C" int mdisp_create_on_stream(mdisp_ctx** out, int device, void* stream) { return create_ctx(out, device, stream, true); }
 
 extern "C" void mdisp_destroy(mdisp_ctx* c)
 {
@@ -67,6 +85,7 @@ extern "C" void mdisp_destroy(mdisp_ctx* c)
         (void)hipStreamDestroy(c->aux);
     }
     if (c->stage) (void)hipFree(c->stage);
+    if (c->sgm_err) (void)hipFree(c->sgm_err);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -92,16 +111,16 @@ int md_ctx_aux(mdisp_ctx* c, md_aux_streams* out)
 
 int md_check_sgm_error(mdisp_ctx* c)
 {
-    int flag = c->sgm_failed ? 1 : 0;
-    c->sgm_failed = false;
-    if (c->sgm_err) {
-        const int* p = c->sgm_err;
-        c->sgm_err = nullptr;
-        int f = 0;
-        MD_HIP(hipMemcpy(&f, p, sizeof(int), hipMemcpyDeviceToHost));
-        flag |= f;
+    if (!c->sgm_pending) return MDISP_OK;
+    c->sgm_pending = false;
+    int f = 0;
+    MD_HIP(hipMemcpy(&f, c->sgm_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (f) {
+        // the word is sticky on the device (no call clears it, so no later call can hide it): clear it only here
+        MD_HIP(hipMemset(c->sgm_err, 0, sizeof(int)));
+        mdisp_set_error("SGM sweep pipeline: a band waited too long for its neighbour (results are invalid)");
+        return MDISP_E_HIP;
     }
-    MD_REQUIRE(flag == 0, MDISP_E_HIP, "SGM sweep pipeline: a strip waited too long for its neighbour (results are invalid)");
     return MDISP_OK;
 }
 
@@ -155,12 +174,6 @@ void* mdisp_ws(mdisp_ctx* c, size_t bytes)
     if (bytes <= c->ws_bytes) return c->ws;
     // the stream may still be reading the old block
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mdisp_set_error("stream sync failed"); return nullptr; }
-    if (c->sgm_err) {
-        // the error word may live in the block that is about to be released: read it now
-        int f = 0;
-        if (hipMemcpy(&f, c->sgm_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && f) c->sgm_failed = true;
-        c->sgm_err = nullptr;
-    }
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
     size_t want = md_align(bytes + bytes / 8, 1 << 20);
     if (hipMalloc(&c->ws, want) != hipSuccess) {

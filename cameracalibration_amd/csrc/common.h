@@ -12,6 +12,9 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 
 void mdisp_set_error(const char* fmt, ...);
+// process-wide scheduling override (mdisp_tuning_set): the value, or -1 when the default applies
+int md_tune(int key);
+void md_tune_clear(int key);
 
 #define MD_HIP(call)                                                                      \
     do {                                                                                  \
@@ -50,8 +53,8 @@ struct mdisp_ctx {
     hipStream_t aux;     // second stream for independent SGM stages of small batches (created on first use)
     hipEvent_t aux_ev[3];
     bool aux_ready;
-    const int* sgm_err;  // device error word of the last pipelined SGM call (0 = fine), or null
-    bool sgm_failed;     // an error word was set when it had to be read early (workspace about to be released)
+    int* sgm_err;        // device word owned by the context: set (never cleared) by a pipelined SGM kernel whose hand-off wait ran out
+    bool sgm_pending;    // a pipelined SGM call has been enqueued since the word was last read
 };
 // after the stream has been synchronised: fails if the last SGM call reported a hand-off timeout
 int md_check_sgm_error(mdisp_ctx* ctx);
@@ -99,7 +102,7 @@ size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch);
 int md_sgm2_slots(const md_sgm_plan& pl);   // u16 elements per pixel of the S volume (64, 128 or 256)
 bool md_sgm2_u8(const md_sgm_plan& pl);
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord,
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
                       const md_aux_streams* aux = nullptr);
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,

@@ -673,7 +673,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     for (int grp = 0; grp < 2; grp++) {
         const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
         pa.firstGroup = grp == 0;
-        if (ndir == 4 && V <= BT_MULTI_MAX_UNITS && !getenv("MDISP_SGBM_BT_SEQUENTIAL")) {
+        if (ndir == 4 && V <= BT_MULTI_MAX_UNITS && md_tune(MDISP_TUNE_SGBM_BT_SEQUENTIAL) <= 0) {
             // small problem: the four directions of the group in one launch
             int total = 0;
             for (int i = 0; i < 4; i++) {
@@ -691,7 +691,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
             continue;
         }
-        if (ndir == 1 && V <= BT_MULTI_MAX_UNITS && !getenv("MDISP_SGBM_BT_SEQUENTIAL")) {
+        if (ndir == 1 && V <= BT_MULTI_MAX_UNITS && md_tune(MDISP_TUNE_SGBM_BT_SEQUENTIAL) <= 0) {
             // small problem, single direction: its serial chain is shorter without the read-modify-write of S
             const int dx = DIRS[grp * 4][0], dy = DIRS[grp * 4][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);

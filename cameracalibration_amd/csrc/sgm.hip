@@ -276,7 +276,7 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm
     plan->off_pad = off; off += plan->pitchR * H;
     plan->off_scratch = off; off += plan->pitchR * H;
     off = md_align(off, 256);
-    plan->use_v2 = md_sgm2_supported(*plan) && !getenv("MDISP_SGM_V1");
+    plan->use_v2 = md_sgm2_supported(*plan) && md_tune(MDISP_TUNE_SGM_PER_DIRECTION) <= 0;
     plan->sstride = plan->use_v2 ? md_sgm2_slots(*plan) : plan->D;
     plan->strideS = md_align((size_t)H * W * plan->sstride * sizeof(u16), 256) / sizeof(u16);
     plan->off_S = off; off += plan->strideS * sizeof(u16) * batch;
@@ -334,7 +334,7 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
         md_aux_streams aux;
         const bool haveAux = md_ctx_aux(ctx, &aux) == MDISP_OK;
         rc = md_sgm2_aggregate(s, pl, base + pl.off_cL, strideL, base + pl.off_cR, strideR, S, pl.strideS, base + pl.off_bnd, pl.batch,
-                               dDisp ? 0 : 1, dDisp, &ctx->sgm_err, haveAux ? &aux : nullptr);
+                               dDisp ? 0 : 1, dDisp, ctx->sgm_err, &ctx->sgm_pending, haveAux ? &aux : nullptr);
         if (rc) return rc;
     } else {
         for (int i = 0; i < pl.batch; i++) {

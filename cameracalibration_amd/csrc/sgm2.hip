@@ -813,10 +813,12 @@ struct ShearArgs {
     Sgm2Args a;
     u8* hand;               // [B][H][nsh][3][LPC*16]: per row and strip, V of m=0, B of m=0, B of m=1
     size_t strideHand;      // bytes per pair
-    int* sync;              // [0] ticket (down) [1] ticket (up) [2] error, [16 + (sweep*B + pair)*nsh + k] progress
+    int* sync;              // [0] ticket (down) [1] ticket (up), [16 + (sweep*B + pair)*nsh + k] progress
+    int* err;               // sticky error word (owned by the context)
     int nsh, cmin, batch;
 };
-constexpr int SHEAR_SPIN_LIMIT = 1 << 22;
+// a hand-off wait gives up after this many ticks of the 100 MHz real-time counter (4 s); it is read every 64 polls
+constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 400000000ull;
 // compute lanes of a sheared-sweep workgroup (+ one communication wave), i.e. strips of NT / LPC columns: 256 lanes for
 // large batches (a row barrier over five waves), 512 for small batches and for the five-path mode (half as many strips:
 // half the hand-off traffic and half the pipeline ramp, at the price of a row barrier over nine waves)
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(SHEAR_NT + 64) void sgm2_shear_kernel(ShearArgs sa)
         const int lane = threadIdx.x - SHEAR_NT, which = lane / LPC, lic = lane % LPC;
         int* progMe = sa.sync + 16 + ((size_t)((UP ? sa.batch : 0) + pair) * sa.nsh + k);
         const int* progNb = progMe + (UP ? -1 : 1);
-        int* errWord = sa.sync + 2;
+        int* errWord = sa.err;
         int seen = 0;
         // m = CW-1 sits in sheared column c0 + CW-1 (down) / c0 (up); m = CW-2 next to it
         const int c15 = UP ? c0 : c0 + CW - 1, c14 = UP ? c0 + 1 : c0 + CW - 2;
@@ -893,10 +895,17 @@ __global__ __launch_bounds__(SHEAR_NT + 64) void sgm2_shear_kernel(ShearArgs sa)
             const int y = ys + sy * i;
             const int need = UP ? H - 1 - y : y;         // rows the neighbour must have published
             if (seen < need) {
+                unsigned long long t0 = 0;
                 for (int it = 0;; it++) {
                     seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (seen >= need) break;
-                    if (it > SHEAR_SPIN_LIMIT || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    bool late = false;
+                    if ((it & 63) == 63) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        late = now - t0 > HANDOFF_TIMEOUT_TICKS;
+                    }
+                    if (late || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         seen = 0x7FFFFFFF;
                         break;
@@ -1165,18 +1174,18 @@ static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin 
 enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2 };
 static int split_max_batch()
 {
-    const char* e = getenv("MDISP_SGM_SPLIT_MAX");
-    return e ? atoi(e) : 4;      // from 5 pairs on the strip pipeline (512-lane strips) is faster
+    const int e = md_tune(MDISP_TUNE_SGM_SPLIT_MAX);
+    return e >= 0 ? e : 4;      // from 5 pairs on the strip pipeline (512-lane strips) is faster
 }
 static int path_waves_max_batch()
 {
-    const char* e = getenv("MDISP_SGM_PATH_WAVES_MAX");
-    return e ? atoi(e) : 4;      // largest batch whose sweeps run one path per wave group (every batch of the latency schedule)
+    const int e = md_tune(MDISP_TUNE_SGM_PATH_WAVES_MAX);
+    return e >= 0 ? e : 4;      // largest batch whose sweeps run one path per wave group (every batch of the latency schedule)
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
     if (!fits_u8(pl)) return SGM2_PREPASS;
-    if (getenv("MDISP_SGM_PREPASS")) return SGM2_PREPASS;
+    if (md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) > 0) return SGM2_PREPASS;
     if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
     return SGM2_SHEAR;
 }
@@ -1184,7 +1193,7 @@ static int sgm2_mode(const md_sgm_plan& pl)
 // lanes per pixel: the sheared kernels run 64 / 128 / 256 disparity slots per pixel, the others always 256
 static int lanes_per_pixel(const md_sgm_plan& pl)
 {
-    if (sgm2_mode(pl) != SGM2_SHEAR || getenv("MDISP_SGM_LANES16")) return 16;
+    if (sgm2_mode(pl) != SGM2_SHEAR || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
 int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
@@ -1192,8 +1201,8 @@ int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
 static int shear_strips(int H, int W, int cw) { return (W + H - 1 + cw - 1) / cw; }
 static int shear_nt(const md_sgm_plan& pl, int batch)
 {
-    const char* e = getenv("MDISP_SGM_STRIP_LANES");
-    if (e) return atoi(e) == 512 ? 512 : 256;
+    const int e = md_tune(MDISP_TUNE_SGM_STRIP_LANES);
+    if (e >= 0) return e == 512 ? 512 : 256;
     return (pl.npaths == 5 || batch <= 32) ? 512 : 256;
 }
 static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
@@ -1266,11 +1275,10 @@ int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int 
 // naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
 // naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, const int** errWord,
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
                       const md_aux_streams* aux)
 {
     Sgm2Args a;
-    if (errWord) *errWord = nullptr;
     const Sgm2Layout l = sgm2_layout(pl, batch);
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
     a.cR = cR; a.pR = pl.pitchR; a.strideR = strideR;
@@ -1341,7 +1349,14 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         const int nt = shear_nt(pl, batch);
         sa.nsh = shear_strips(pl.H, pl.W, nt / l.lpc); sa.cmin = -(pl.H - 1); sa.batch = batch;
         MD_HIP(hipMemsetAsync(sa.sync, 0, l.syncBytes, s));
-        if (errWord) *errWord = sa.sync + 2;
+        // the error word belongs to the caller and is never cleared here: a timeout of an earlier call on the same
+        // stream stays visible until the host reads it
+        sa.err = errWord;
+        if (usedErrWord) *usedErrWord = true;
+        if (md_tune(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
+            md_tune_clear(MDISP_TUNE_SGM_PLANT_ERROR);
+            MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
+        }
         if (nt == 512) {
             if (l.lpc == 4) MD_TRY((launch_shear<4, 512>(s, pl, sa, batch, naturalOut)));
             else if (l.lpc == 8) MD_TRY((launch_shear<8, 512>(s, pl, sa, batch, naturalOut)));

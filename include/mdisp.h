@@ -152,6 +152,9 @@ int         mdisp_device_count(void);
 /* device < 0 selects the current HIP device.  stream: a hipStream_t to enqueue on, or NULL to
  * let the context create its own. */
 int  mdisp_create(mdisp_ctx** ctx, int device, void* stream);
+/* Same, but `stream` is always the stream to enqueue on, the legacy default stream (NULL) included: for callers
+ * whose producers run on the default stream and rely on its ordering.  No counterpart in the reference. */
+int  mdisp_create_on_stream(mdisp_ctx** ctx, int device, void* stream);
 void mdisp_destroy(mdisp_ctx* ctx);
 int  mdisp_synchronize(mdisp_ctx* ctx);
 
@@ -383,6 +386,25 @@ int mdisp_last_kernel_ms(mdisp_ctx*, int which, float* ms);
  * quotes it next to the nominal HBM peak. */
 int mdisp_copy_bandwidth_dev(mdisp_ctx*, void* d_dst, const void* d_src, size_t bytes, int reps, float* gb_per_s);
 int mdisp_enable_timing(mdisp_ctx*, int on);
+
+/* Diagnostic aid, no counterpart in the reference: process-wide scheduling overrides that let the tests reach every
+ * schedule of the SGM code at small image sizes (by default the library picks a schedule from the image and batch
+ * size alone; it never reads the environment).  value < 0 restores the default.  Not synchronised with calls that
+ * are in flight on other threads: set it while no compute call is running. */
+enum {
+    MDISP_TUNE_SGM_SPLIT_MAX = 0,      /* largest batch on the latency schedule (default 4)                         */
+    MDISP_TUNE_SGM_PATH_WAVES_MAX = 1, /* largest batch whose sweeps run one path per wave group (default 4)        */
+    MDISP_TUNE_SGM_STRIP_LANES = 2,    /* 256 or 512 compute lanes per sheared strip                                */
+    MDISP_TUNE_SGM_FORCE_PREPASS = 3,  /* 1: upright strips + diagonal pre-pass even when byte path states fit      */
+    MDISP_TUNE_SGM_LANES16 = 4,        /* 1: sixteen lanes per pixel whatever the disparity count                   */
+    MDISP_TUNE_SGM_PER_DIRECTION = 5,  /* 1: one kernel per path direction (the fallback of unsupported shapes)     */
+    MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other  */
+    MDISP_TUNE_SGM_PIPELINE = 7,       /* batches: 0 = row bands with four paths per sweep (default), 1 = sheared strips with a separate horizontal scan */
+    MDISP_TUNE_SGM_PLANT_ERROR = 8,    /* 1: the next pipelined SGM call finds its hand-off error word already set  */
+    MDISP_TUNE_COUNT = 9
+};
+int mdisp_tuning_set(int key, int value);
+int mdisp_tuning_get(int key);
 
 /* ---- synthetic rectified pair generator used by the tests and the benchmark (host) ----
  * right = box-filtered white noise, left(x,y) = right(reflect(x - d_gt), y) + noise in [-2,2];

@@ -199,3 +199,61 @@ def test_row_bands_with_exchanged_statistics(api, gif, win, r2):
                                   stats=(mm, sm))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), full)
+
+
+# ---- the large-pair configuration's own parameters: SKWGIF, winSize 35, r2 15, eps 0.01, 512 disparities ----
+
+@pytest.mark.parametrize("shape", [(60, 80), (96, 160), (41, 203)])
+def test_guided_filter_skwgif2_wide_windows(api, orc, shape):
+    # the wide-window marching kernel (row re-fetch + prefix sums) under the steer-weighted variant
+    guide = _textured(11, *shape)
+    rng = np.random.default_rng(12)
+    sw = orc.steer_filter(guide)
+    for P in (rng.integers(0, 9, shape, dtype=np.uint8), rng.integers(0, 256, shape, dtype=np.uint8)):
+        got = api.getGuidedFilter_skwgif2(guide, P, sw, 35, 15, 0.01, 0.1)
+        exp = orc.guided_filter(guide, P, 35, 0.01, orc.SKWGIF, steerW=sw, r2=15, namuda=0.1)
+        assert np.abs(got - exp).max() <= TOL
+
+
+def test_asw_gifs_large_pair_parameters_against_oracle(api, orc):
+    # asw_gifs(param{0..511, win 35}, 0.01, SKWGIF, r2 15) at a size the oracle affords: 512 slices of 96x160
+    # (the REFLECT pad of the right image makes any width legal, methods_disp.cpp:1005)
+    H, W, minD, maxD, win, r2 = 96, 160, 0, 511, 35, 15
+    L, R, _ = api.synth_pair(0x5EED0005, H, W, 64)
+    pad = orc.pad_reflect_lr(R, maxD, 0)
+    cL, cP = orc.census(L), orc.census(pad)
+    costs = np.stack([orc.hamming(cL, np.ascontiguousarray(cP[:, maxD - d:maxD - d + W])) for d in range(minD, maxD + 1)]).astype(np.float32)
+    p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=win, minDisparity=minD, maxDisparity=maxD, isDispLeft=True)
+    got = api.asw_gifs(p, 0.01, api.SKWGIF, r2, 0.1, 0.5, api.COST_CENSUS)
+    exp, filt = orc.asw_gifs(L, costs, minD, win, 0.01, orc.SKWGIF, r2, 0.1, want_filtered=True)
+    assert filt.shape[0] == 512
+    assert got.min() >= minD and got.max() <= maxD
+    assert (got == exp).mean() > 0.999
+    assert _tie_aware_equal(got, exp, filt, minD)
+
+
+def test_large_pair_row_band_at_full_size(api):
+    # 7680x4320, D = 512, SKWGIF, winSize 35, r2 15: one GPU's band of a row-band split, checked by size-independent
+    # properties -- its rows equal the rows of the full-image call bit for bit, every value is a candidate disparity,
+    # and a finer split of the same rows gives the same map
+    import torch
+    H, W, D, win, r2 = 4320, 7680, 512, 35, 15
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+    dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+
+    def run(bands):
+        out = torch.full((H, W), -1.0, dtype=torch.float32, device="cuda")
+        for (b, e) in bands:
+            api.asw_gifs_band_dev(dl.data_ptr(), dr.data_ptr(), H, W, W, win, 0, D - 1, True, 0.01, api.SKWGIF, r2, 0.1, b, e, out.data_ptr())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    b0, b1 = 3 * (H // 8), 4 * (H // 8)              # band 3 of 8
+    full = run([(0, H)])
+    assert full.min() >= 0 and full.max() <= D - 1
+    band = run([(b0, b1)])
+    assert (band[:b0] == -1).all() and (band[b1:] == -1).all()
+    assert np.array_equal(band[b0:b1], full[b0:b1])
+    split = run([(b0, b0 + 100), (b0 + 100, b0 + 101), (b0 + 101, b1)])
+    assert (split[b0:b1] == band[b0:b1]).mean() >= 0.999
+    assert np.array_equal(split[b0:b1], band[b0:b1])

@@ -167,16 +167,17 @@ SGM_CASES = [
 # wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
 # with the strip width of small batches (512 lanes per workgroup) or of large ones (256)
 @pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips"])
-def sgm_schedule(request, monkeypatch):
-    monkeypatch.delenv("MDISP_SGM_SPLIT_MAX", raising=False)
-    monkeypatch.delenv("MDISP_SGM_STRIP_LANES", raising=False)
-    monkeypatch.delenv("MDISP_SGM_PATH_WAVES_MAX", raising=False)
+def sgm_schedule(request):
+    from cameracalibration_amd import _lib
+    _lib.tuning_reset()
     if request.param == "latency, one wave group":
-        monkeypatch.setenv("MDISP_SGM_PATH_WAVES_MAX", "0")
+        _lib.tuning_set(_lib.TUNE_SGM_PATH_WAVES_MAX, 0)
     elif request.param != "latency":
-        monkeypatch.setenv("MDISP_SGM_SPLIT_MAX", "0")
-        monkeypatch.setenv("MDISP_SGM_STRIP_LANES", "256" if "narrow" in request.param else "512")
-    return request.param
+        _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
+        _lib.tuning_set(_lib.TUNE_SGM_PIPELINE, 1)
+        _lib.tuning_set(_lib.TUNE_SGM_STRIP_LANES, 256 if "narrow" in request.param else 512)
+    yield request.param
+    _lib.tuning_reset()
 
 
 @pytest.mark.parametrize("case", SGM_CASES)
@@ -358,3 +359,33 @@ def test_rectification_maps_built_on_the_gpu(api, orc):
     g1, g2 = maps.download()
     h1, h2 = api.initUndistortRectifyMap(m["StereoCalib_K1"], m["StereoCalib_D1"], m["Rectify_R1"], m["Rectify_P1"], (2560, 1440))
     assert np.array_equal(g1, h1) and np.array_equal(g2, h2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_sgm_handoff_timeout_is_not_lost_between_chunks(api, orc, pipeline):
+    # a hand-off timeout in the FIRST chunk of a chunked batch must still fail the call: the error word is owned by the
+    # context and no later chunk clears it.  The word is planted before chunk 0's kernels; afterwards the context works again.
+    from cameracalibration_amd import _lib
+    from cameracalibration_amd._lib import MdispError, E_HIP
+    H, W, D, n = 36, 72, 48, 9
+    p = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+    Ls, Rs = [], []
+    for i in range(n):
+        L, R, _ = api.synth_pair(0x5EED0201 + 2 * i, H, W, D)
+        Ls.append(L)
+        Rs.append(R)
+    _lib.tuning_reset()
+    try:
+        _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)          # every chunk goes through a pipelined schedule
+        _lib.tuning_set(_lib.TUNE_SGM_PIPELINE, pipeline)
+        _lib.tuning_set(_lib.TUNE_SGM_PLANT_ERROR, 1)
+        with pytest.raises(MdispError) as e:
+            api.sgbm_compute_batch(Ls, Rs, p, 3)
+        assert e.value.code == E_HIP
+        assert _lib.load().mdisp_tuning_get(_lib.TUNE_SGM_PLANT_ERROR) == -1
+        got = api.sgbm_compute_batch(Ls, Rs, p, 3)
+        for i in range(n):
+            assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], 0, D, 8, 32, 10, 1, 8, 1))
+    finally:
+        _lib.tuning_reset()

@@ -36,14 +36,15 @@ CASES = [
 
 
 # small problems run the four directions of a group in one launch; large ones one direction per launch with the
-# running group sum kept in memory -- the environment switch selects the second schedule at test sizes
+# running group sum kept in memory -- the tuning switch selects the second schedule at test sizes
 @pytest.fixture(params=["one launch per group", "one launch per direction"])
-def bt_schedule(request, monkeypatch):
+def bt_schedule(request):
+    from cameracalibration_amd import _lib
+    _lib.tuning_reset()
     if request.param == "one launch per direction":
-        monkeypatch.setenv("MDISP_SGBM_BT_SEQUENTIAL", "1")
-    else:
-        monkeypatch.delenv("MDISP_SGBM_BT_SEQUENTIAL", raising=False)
-    return request.param
+        _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 1)
+    yield request.param
+    _lib.tuning_reset()
 
 
 @pytest.mark.parametrize("case", CASES)
