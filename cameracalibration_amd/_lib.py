@@ -59,7 +59,7 @@ EXPORTS = [
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
-    "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
+    "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
 ]
 
@@ -132,6 +132,7 @@ def load():
     lib.mdisp_sgbm_batch_workspace_bytes.restype = C.c_size_t
     lib.mdisp_sgbm_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_census_stereo_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
+    lib.mdisp_census_stereo_dev_noalloc.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
     lib.mdisp_asw_gifs_band_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_double, C.c_int, C.c_int, C.c_double,
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.mdisp_asw_gifs_band_stats_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]

@@ -3,6 +3,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdlib.h>
+#include <mutex>
 #include <new>
 
 static thread_local char g_err[512] = "";
@@ -36,6 +37,28 @@ extern "C" int mdisp_device_count(void)
     return n;
 }
 
+// Scratch of mdisp_census_stereo_dev_noalloc, the entry point that allocates nothing: a file-scope device array that
+// every GPU the library runs on holds until the process ends.  In host code the array's name is only a stand-in for
+// the symbol; its address on a device comes from hipGetSymbolAddress with that device current (every GPU has its own
+// copy at its own address) and only that pointer is ever handed to kernels.
+static __device__ __align__(256) unsigned char scratch[MDISP_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static u8* g_scratch_ptr[64] = {};
+// `device` must be the current device
+static int scratch_of_device(int device, u8** out)
+{
+    MD_REQUIRE(device >= 0 && device < 64, MDISP_E_BADARG, "device %d beyond the 64 the scratch table holds", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        MD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        MD_REQUIRE(p, MDISP_E_HIP, "hipGetSymbolAddress returned a null scratch address");
+        g_scratch_ptr[device] = (u8*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return MDISP_OK;
+}
+
 static int create_ctx(mdisp_ctx** out, int device, void* stream, bool useGiven)
 {
     MD_REQUIRE(out, MDISP_E_BADARG, "null context pointer");
@@ -64,6 +87,10 @@ static int create_ctx(mdisp_ctx** out, int device, void* stream, bool useGiven)
     // the sticky hand-off error word of the pipelined SGM kernels (one 256-byte line of its own)
     if (hipMalloc((void**)&c->sgm_err, 256) != hipSuccess || hipMemset(c->sgm_err, 0, 256) != hipSuccess) {
         mdisp_set_error("hipMalloc of the context's status word failed"); delete c; return MDISP_E_NOMEM;
+    }
+    {
+        const int rc = scratch_of_device(device, &c->noalloc_scratch);
+        if (rc) { (void)hipFree(c->sgm_err); delete c; return rc; }
     }
     *out = c;
     return MDISP_OK;
@@ -466,6 +493,32 @@ extern "C" int mdisp_census_stereo_dev(mdisp_ctx* c, const uint8_t* d_left, cons
     const u8* other = p->isDispLeft ? d_right : d_left;
     return census_stereo_body(c, ref, other, pitch, rows, cols, p, census_method, agg_mode, base + o_pad, pitchP,
                               base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp, base + o_gif);
+}
+
+// The same call without any allocation: the three padded-width planes and the census scratch live in the library's
+// file-scope device array instead of the context's grow-only workspace.
+extern "C" int mdisp_census_stereo_dev_noalloc(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols,
+                                               size_t pitch, const mdisp_param* p, int census_method, int agg_mode, double* d_disp)
+{
+    MD_REQUIRE(c && d_left && d_right && d_disp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(rows > 0 && cols > 0 && pitch >= (size_t)cols && pitch % 4 == 0, MDISP_E_BADARG,
+               "bad geometry (pitch must be a multiple of 4 and >= cols)");
+    MD_REQUIRE(p->winSize % 2 != 0 && p->winSize > 0 && p->minDisparity >= 0 && p->maxDisparity >= p->minDisparity,
+               MDISP_E_BADARG, "bad function parameters, please check image and window size.");
+    MD_REQUIRE(agg_mode != MDISP_AGG_GUIDED, MDISP_E_UNSUPPORTED,
+               "guided aggregation needs per-slice planes far beyond the fixed scratch: use mdisp_census_stereo_dev");
+    const size_t pitchP = md_align((size_t)cols + p->maxDisparity, 256);
+    Carver cv;
+    size_t o_pad = cv.take(pitchP * rows), o_cr = cv.take(pitchP * rows), o_cp = cv.take(pitchP * rows), o_scr = cv.take(pitchP * rows + MD_CENSUS_SCRATCH_TAIL);
+    MD_REQUIRE(cv.off <= (size_t)MDISP_NOALLOC_SCRATCH_BYTES, MDISP_E_RANGE,
+               "%dx%d with maxDisparity %d needs %zu bytes of scratch, the fixed array holds %u", cols, rows, p->maxDisparity, cv.off,
+               (unsigned)MDISP_NOALLOC_SCRATCH_BYTES);
+    MD_HIP(hipSetDevice(c->device));
+    u8* base = c->noalloc_scratch;     // the device address of `scratch` on the context's GPU, never the symbol itself
+    const u8* ref = p->isDispLeft ? d_left : d_right;
+    const u8* other = p->isDispLeft ? d_right : d_left;
+    return census_stereo_body(c, ref, other, pitch, rows, cols, p, census_method, agg_mode, base + o_pad, pitchP,
+                              base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp, nullptr);
 }
 
 static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out, bool inte)

@@ -353,6 +353,17 @@ int mdisp_sgbm_batch_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_rig
 int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                             const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
 
+/* mdisp_census_stereo_dev for callers that cannot allocate: code under HIP graph capture, tight serving loops and
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments and results as
+ * mdisp_census_stereo_dev, but every intermediate plane lives in a fixed device array of MDISP_NOALLOC_SCRATCH_BYTES
+ * inside the library (held by every GPU the library runs on until the process ends), and the call performs no
+ * hipMalloc / hipFree.  Needs 4 * rows * roundup(cols + maxDisparity, 256) + 2048 bytes of it: larger problems fail
+ * with MDISP_E_RANGE, MDISP_AGG_GUIDED with MDISP_E_UNSUPPORTED.  All calls on one GPU share the array: calls that
+ * overlap in time on one GPU (two contexts, two streams) race; calls on one context are ordered by its stream. */
+#define MDISP_NOALLOC_SCRATCH_BYTES (16u << 20)
+int mdisp_census_stereo_dev_noalloc(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                    const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
+
 /* asw_gifs (methods_disp.h:66) on device buffers, restricted to the output rows [row_begin, row_end):
  * the share of one GPU when a large pair is split into horizontal row bands.  d_left / d_right hold
  * the WHOLE images (every GPU keeps a copy); d_disp is a float rows x cols map of which only the
