@@ -542,25 +542,9 @@ struct ShearArgs {
     int* err;               // sticky error word (owned by the context)
     int nsh, cmin, batch;
 };
-// a hand-off wait gives up after this many ticks of the 100 MHz real-time counter (4 s); it is read every 64 polls
-constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 400000000ull;
 // compute lanes of a sheared-sweep workgroup (+ one communication wave), i.e. strips of NT / LPC columns: 256 lanes for
 // large batches (a row barrier over five waves), 512 for small batches and for the five-path mode (half as many strips:
 // half the hand-off traffic and half the pipeline ramp, at the price of a row barrier over nine waves)
-
-__device__ __forceinline__ void hand_store(u8* p, const uint4& v)
-{
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint4 hand_load(const u8* p)
-{
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-}
 
 template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, bool FIVE = false, int SHEAR_NT = 256>
 __global__ __launch_bounds__(SHEAR_NT + 64) void sgm2_shear_kernel(ShearArgs sa)
@@ -896,7 +880,9 @@ static bool fits_u8(const md_sgm_plan& pl) { return 8 * pl.costWin * pl.costWin 
 //   PREPASS  upright strips + diagonal pre-pass, one sweep after the other (16-bit path states, or on request)
 //   SPLIT    upright strips, the two sweeps side by side on two streams and a summing winner-take-all: a batch of
 //            a few pairs cannot fill the strip pipeline, so the latency of one pair counts
-enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2 };
+//   ROWS     row bands with four paths per sweep (sgm3.hip): no horizontal volumes, one cost evaluation per sweep;
+//            the throughput mode for eight paths (SHEAR remains for five paths and on request)
+enum { SGM2_SHEAR = 0, SGM2_PREPASS = 1, SGM2_SPLIT = 2, SGM2_ROWS = 3 };
 static int split_max_batch()
 {
     const int e = md_tune(MDISP_TUNE_SGM_SPLIT_MAX);
@@ -912,13 +898,15 @@ static int sgm2_mode(const md_sgm_plan& pl)
     if (!fits_u8(pl)) return SGM2_PREPASS;
     if (md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) > 0) return SGM2_PREPASS;
     if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
+    if (pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1) return SGM2_ROWS;
     return SGM2_SHEAR;
 }
 
 // lanes per pixel: the sheared kernels run 64 / 128 / 256 disparity slots per pixel, the others always 256
 static int lanes_per_pixel(const md_sgm_plan& pl)
 {
-    if (sgm2_mode(pl) != SGM2_SHEAR || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
+    const int mode = sgm2_mode(pl);
+    if ((mode != SGM2_SHEAR && mode != SGM2_ROWS) || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
 int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
@@ -930,6 +918,19 @@ static int shear_nt(const md_sgm_plan& pl, int batch)
     if (e >= 0) return e == 512 ? 512 : 256;
     return (pl.npaths == 5 || batch <= 32) ? 512 : 256;
 }
+// sgm3.hip
+int md_sgm3_bands(int H, int lpc, int nt);
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int nt);
+size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
+int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int nt,
+                   int naturalOut, bool s4b);
+static int rows_nt(const md_sgm_plan& pl, int batch)
+{
+    const int e = md_tune(MDISP_TUNE_SGM_STRIP_LANES);
+    if (e >= 0) return e == 512 ? 512 : 256;
+    return 256;
+}
+
 static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
 static size_t shear_sync_bytes(int H, int W, int batch, int lpc, int nt)
 { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, nt / lpc)) * sizeof(int), 256); }
@@ -945,11 +946,12 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
     l.cw = CW;
     l.nstrips = (pl.W + l.cw - 1) / l.cw;
     if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // hand-off rows (sized for the narrower strips)
+    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // last-row states of every band (sized for the lower bands)
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
-    l.oneH = md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
+    l.oneH = l.mode == SGM2_ROWS ? 0 : md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
     l.oneS2 = l.mode == SGM2_SPLIT ? md_align((size_t)pl.H * pl.W * 256 * sizeof(u16), 256) : 0;
-    l.syncBytes = shear_sync_bytes(pl.H, pl.W, batch, l.lpc, 256);
+    l.syncBytes = l.mode == SGM2_ROWS ? md_sgm3_sync_bytes(pl.H, batch, l.lpc, 256) : shear_sync_bytes(pl.H, pl.W, batch, l.lpc, 256);
     return l;
 }
 
@@ -1066,6 +1068,16 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
 #undef SGM2_SPLIT3_LAUNCH
 #undef SGM2_SPLIT_LAUNCH
         MD_HIP(hipGetLastError());
+    } else if (l.mode == SGM2_ROWS) {
+        int* sync = (int*)afterRec;
+        MD_HIP(hipMemsetAsync(sync, 0, l.syncBytes, s));
+        if (usedErrWord) *usedErrWord = true;
+        if (md_tune(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
+            md_tune_clear(MDISP_TUNE_SGM_PLANT_ERROR);
+            MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
+        }
+        const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, rows_nt(pl, batch), naturalOut, s4b));
     } else if (l.mode == SGM2_SHEAR) {
         ShearArgs sa;
         sa.a = a;

@@ -1,0 +1,312 @@
+// Row-band semi-global matching for gfx950: FOUR paths per sweep, two sweeps, no horizontal volumes.
+//
+//   down sweep:  -> (1,0)   \ (1,1)    v (0,1)    / (-1,1)      -> four-path partial sum S4 (one byte or u16 per slot)
+//   up sweep:    <- (-1,0)  (-1,-1)    ^ (0,-1)   (1,-1)        -> S4 + four more = S8 in registers -> winner-take-all
+//
+// Both sweeps are the same program in "logical" coordinates (u, v): the up sweep mirrors both axes
+// (x = W-1-u, y = H-1-v), which turns its four directions into the down sweep's.  In logical coordinates a pixel
+// (u, v) depends on (u-1, v), (u-1, v-1), (u, v-1) and (u+1, v-1).  With the time skew t = u + 2v all four
+// predecessors are one to three steps old, so a workgroup owns a BAND of image rows (one row per "slot": the LPC lanes
+// that share a pixel), every slot marches along its row, and slot j runs two pixels behind slot j-1:
+//   ->   state stays in the slot's registers,
+//   /    needs the state of (u+1, v-1): what slot j-1 produced in the previous step,
+//   v    needs (u, v-1):   produced two steps ago,
+//   \    needs (u-1, v-1): produced three steps ago.
+// Each step a slot publishes the three states of its pixel in LDS (bytes, double-buffered by step parity) and the slot
+// below reads all three one step later: it uses the / state at once and keeps the other two in registers for one and
+// two more steps.  The matching cost is evaluated once per pixel and sweep and shared by the four paths; nothing but
+// the four-path sum (and, per band, the last row's states) ever reaches memory.
+//
+// Bands form a pipeline along the sweep: the last slot of band b hands its three states per pixel to slot 0 of band
+// b+1 through global memory, and band b+1 follows about 2*SLOTS steps behind.  The protocol is the one of the sheared
+// strips in sgm2.hip: workgroups take a ticket at start, tickets enumerate bands in dependency order (all pairs of band
+// b before band b+1), so a workgroup only waits for one that started earlier; an extra "communication" wave per
+// workgroup does the exchange (agent-scope write-through stores, drain, then the progress word; agent-scope loads on
+// the consumer side, parked in LDS one step ahead); every wait is bounded and reports through a sticky error word.
+#include "sgm_lanes.h"
+
+namespace {
+
+struct RowArgs {
+    Sgm2Args a;
+    u8* hand;               // [B][nb][W][3][LPC*16] bytes: states (v, \, /) of the last row of every band, per pixel
+    size_t strideHand;      // bytes per pair
+    int* sync;              // [0] ticket (down) [1] ticket (up), [16 + (sweep*B + pair)*nb + band] pixels published by the band's last row
+    int* err;               // sticky error word (owned by the caller)
+    int nb, batch;          // bands per image, pairs per launch
+    int band0;              // first band this launch runs (its predecessor's states and progress word are already in place)
+};
+
+template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, int NT>
+__global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
+{
+    constexpr int SLOTS = NT / LPC, DP = LPC * DPL, SW = LPC * 4;
+    const Sgm2Args& a = ra.a;
+    __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][bytes of the pixel's LPC lanes]
+    __shared__ u32 hin[2][3][SW];           // the band above's states for slot 0, same parity rule
+    __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * 8 : 1];
+    __shared__ u32 exclMask[FUSE ? 19 : 1][NR];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[UP ? 1 : 0], 1);
+    if (FUSE) init_excl_mask(exclMask);
+    __syncthreads();
+    const int ticket = s_ticket;
+    const int ord = ticket / ra.batch, pair = ticket - ord * ra.batch;
+    const int band = ra.band0 + ord;                      // bands in dependency order
+    const int H = a.H, W = a.W;
+    const int T = W + 2 * (SLOTS - 1);                    // steps: slot j works on u = t - 2j
+    u8* hand = ra.hand + (size_t)pair * ra.strideHand;
+    const bool hasPrev = band > 0, hasNext = band + 1 < ra.nb;
+
+    if (threadIdx.x >= NT) {
+        // ---- communication wave: publishes the last slot's states one step behind the compute waves and fetches
+        // the states slot 0 will consume one step ahead of them
+        const int lane = threadIdx.x - NT, which = lane / LPC, lic = lane % LPC;
+        int* progMe = ra.sync + 16 + ((size_t)((UP ? ra.batch : 0) + pair) * ra.nb + band);
+        const int* progNb = progMe - 1;
+        int* errWord = ra.err;
+        int seen = 0;
+        auto hand_slot = [&](int bnd, int u, int wh) -> u8* { return hand + ((((size_t)bnd * W + u) * 3 + wh) * DP + lic * 16); };
+        // slot 0 consumes in step i (i >= -1) the states of pixel i + 1 of the row above
+        auto wants = [&](int i) -> bool { return hasPrev && which < 3 && i + 1 < W; };
+        auto request = [&](int i, uint4& w) {
+            const bool mine = wants(i);
+            if (!__any(mine)) return;
+            const int need = i + 2;                       // pixels the band above must have published
+            if (seen < need) {
+                unsigned long long t0 = 0;
+                for (int it = 0;; it++) {
+                    seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= need) break;
+                    bool late = false;
+                    if ((it & 63) == 63) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        late = now - t0 > HANDOFF_TIMEOUT_TICKS;
+                    }
+                    if (late || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(errWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        seen = 0x7FFFFFFF;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            }
+            if (mine) w = hand_load(hand_slot(band - 1, i + 1, which));
+        };
+        auto park = [&](int i, const uint4& w) {          // hand the fetched states of step i to slot 0
+            if (wants(i)) *reinterpret_cast<uint4*>(&hin[(i + 1) & 1][which][lic * 4]) = w;
+        };
+        auto send = [&](int t) {                           // step t has been computed: the last slot's states are in st[t & 1]
+            const int u = t - 2 * (SLOTS - 1);
+            if (hasNext && which < 3 && u >= 0 && u < W)
+                hand_store(hand_slot(band, u, which), *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][lic * 4]));
+        };
+        auto announce = [&](int t) {                       // the states of steps up to t are in memory
+            const int u = t - 2 * (SLOTS - 1);
+            if (hasNext && lane == 0 && u >= 0) __hip_atomic_store(progMe, min(u, W - 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // Software pipeline, one step per pixel, that never waits for an operation issued in the same step: step t first
+        // drains what step t-1 issued (stores of step t-2's states, loads for step t+1, a sample of the neighbour's
+        // progress), then announces step t-2, sends step t-1, parks step t+1's states in LDS and requests step t+2's.
+        uint4 w = make_uint4(0, 0, 0, 0);
+        request(-1, w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park(-1, w);
+        request(0, w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park(0, w);
+        request(1, w);
+        int sample = 0;
+        __syncthreads();      // the states of pixels 0 and 1 of the row above are parked
+        __syncthreads();      // slot 0 has taken pixel 0's
+        for (int t = 0; t < T; t++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            seen = max(seen, sample);
+            if (t >= 2) announce(t - 2);
+            if (t >= 1) send(t - 1);
+            if (t + 1 < T) park(t + 1, w);
+            if (t + 2 < T) request(t + 2, w);
+            if (hasPrev) sample = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
+        send(T - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        announce(T - 1);
+        return;
+    }
+
+    // ---- compute waves ----
+    const int lic = threadIdx.x % LPC, j = threadIdx.x / LPC;
+    const int v = band * SLOTS + j;
+    const bool rowOk = v < H;
+    const int vc = min(v, H - 1);                         // idle slots of the last band request (and drop) a valid row
+    const int y = UP ? H - 1 - vc : vc;
+    const bool top = v == 0;
+    const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
+    const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR + (a.maxD - a.minD - lic * DPL - 15);
+    u8* Srow = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)y * W * (S4B ? DP : 2 * DP) + lic * (S4B ? 16 : 32);
+    const size_t recRow = (size_t)pair * a.strideRec + (size_t)y * W;
+    u32 tail[NR];
+    make_tail(lic, a.D, tail);
+    const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
+    auto fresh = [&](u32 (&N)[NR]) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) N[q] = TAIL ? tail[q] : 0u;
+    };
+    auto from_bytes = [&](const uint4& w, u32 (&N)[NR]) {     // all-zero bytes are the state of a path that starts here
+        unpack_bytes(w, N);
+        if (TAIL) {
+#pragma unroll
+            for (int q = 0; q < NR; q++) N[q] |= tail[q];
+        }
+    };
+    // where this slot reads the row above's states: slot j-1's LDS entry, or (slot 0) what the communication wave parked;
+    // both alternate with the parity of t + 1
+    const u32* aboveBase = j > 0 ? &st[0][j - 1][0][lic * 4] : &hin[0][0][lic * 4];
+    const int aboveStride = j > 0 ? SLOTS * 3 * SW : 3 * SW;
+
+    u32 Nh[NR];                        // the path that runs along the row
+    fresh(Nh);
+    u32 clw = 0; uint4 rb = make_uint4(0, 0, 0, 0), sb = make_uint4(0, 0, 0, 0);
+    u32 Sn[NR];
+    zero8(Sn);
+    int xf = 0;                        // the column the operands in flight belong to
+    auto fetch = [&](int t) {          // unconditional: out-of-range steps ask for the nearest pixel of the row again
+        const int u = min(max(t - 2 * j, 0), W - 1);
+        xf = UP ? W - 1 - u : u;
+        clw = *reinterpret_cast<const u32*>(cLrow + (xf & ~3));
+        __builtin_memcpy(&rb, cRrow + xf, 16);
+        if (UP) {
+            if (S4B) sb = load16_stream(Srow + (size_t)xf * DP);
+            else load8_stream(reinterpret_cast<const u16*>(Srow + (size_t)xf * 2 * DP), Sn);
+        }
+    };
+    fetch(0);
+    // states of the row above kept in registers: the vertical one for one step, the diagonal one for two.  The loop is
+    // unrolled by two so that "keep" is a matter of which register set a step names, not of copies.
+    uint4 V0 = make_uint4(0, 0, 0, 0), V1 = V0, DA = V0, DB = V0;
+    __syncthreads();                   // the communication wave has parked pixel 0 and pixel 1 of the row above
+    if (j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
+        V0 = *reinterpret_cast<const uint4*>(&hin[0][0][lic * 4]);
+        DB = *reinterpret_cast<const uint4*>(&hin[0][1][lic * 4]);
+    }
+    __syncthreads();
+    // one step: Vuse was read in the previous step, D two steps ago; Vfill / D receive what the row above published in
+    // the previous step (D only after its old contents have been consumed)
+    auto step = [&](int t, uint4& Vuse, uint4& Vfill, uint4& D) {
+        const int u = t - 2 * j;
+        const bool active = rowOk && u >= 0 && u < W;
+        const int x = xf;
+        u32 C[NR], L[NR], Sacc[NR];
+        cost_from_operands(census_byte(clw, x), rb, C);
+        if (UP) {
+            if (S4B) unpack_bytes(sb, Sacc);
+            else {
+#pragma unroll
+                for (int q = 0; q < NR; q++) Sacc[q] = Sn[q];
+            }
+        }
+        fetch(t + 1);
+        const u32* above = aboveBase + ((t + 1) & 1) * aboveStride;
+        Vfill = *reinterpret_cast<const uint4*>(above);
+        uint4 curA = *reinterpret_cast<const uint4*>(above + 2 * SW);      // anti-diagonal: used at once
+        if (active) {
+            // paths that start at this pixel (image border): rare, so the per-lane selects sit behind a wave-level test
+            const bool firstCol = u == 0, lastCol = u == W - 1;
+            if (__any(top || firstCol || lastCol)) {
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                if (top || lastCol) curA = z;
+                if (top) Vuse = z;
+                if (top || firstCol) D = z;
+                if (firstCol) fresh(Nh);
+            }
+            sgm_step<TAIL, LPC>(Nh, C, P1P1, P2P2, tail, L, lic);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = UP ? pkadd(Sacc[q], L[q]) : L[q];
+            u32 N[NR];
+            from_bytes(curA, N);
+            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            *reinterpret_cast<uint4*>(&st[t & 1][j][2][lic * 4]) = pack_bytes(N);
+            from_bytes(Vuse, N);
+            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            *reinterpret_cast<uint4*>(&st[t & 1][j][0][lic * 4]) = pack_bytes(N);
+            from_bytes(D, N);
+            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+#pragma unroll
+            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            *reinterpret_cast<uint4*>(&st[t & 1][j][1][lic * 4]) = pack_bytes(N);
+            if (!UP) {
+                if (S4B) store16_stream(Srow + (size_t)x * DP, pack_bytes(Sacc));
+                else store8_stream(reinterpret_cast<u16*>(Srow + (size_t)x * 2 * DP), Sacc);
+            } else if (FUSE) {
+                fused_wta<TAIL, LPC>(a, Sacc, tail, lic, &srow[j][0], exclMask, recRow + x);
+            } else {
+                // volume export: the full sum in natural disparity order, in place of the four-path sum
+                u32 nat[NR];
+#pragma unroll
+                for (int g = 0; g < NR / 2; g++) {
+                    nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+                    nat[g + 4] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                }
+                store8(reinterpret_cast<u16*>(Srow + (size_t)x * 2 * DP), nat);
+            }
+        }
+        D = *reinterpret_cast<const uint4*>(above + SW);
+        __syncthreads();   // st[t & 1] complete before the next step reads it
+    };
+    int t = 0;
+    for (; t + 2 <= T; t += 2) {
+        step(t, V0, V1, DA);
+        step(t + 1, V1, V0, DB);
+    }
+    if (t < T) step(t, V0, V1, DA);
+}
+
+template <int LPC, int NT>
+int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, int naturalOut, bool s4b, bool tail)
+{
+    const dim3 g((unsigned)nbands * ra.batch);
+#define SGM3_LAUNCH(TAILV, S4BV)                                                                         \
+    do {                                                                                                 \
+        sgm3_rows_kernel<false, TAILV, false, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);                  \
+        if (naturalOut) sgm3_rows_kernel<true, TAILV, false, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);   \
+        else sgm3_rows_kernel<true, TAILV, true, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);               \
+    } while (0)
+    if (tail) { if (s4b) SGM3_LAUNCH(true, true); else SGM3_LAUNCH(true, false); }
+    else { if (s4b) SGM3_LAUNCH(false, true); else SGM3_LAUNCH(false, false); }
+#undef SGM3_LAUNCH
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+}  // namespace
+
+int md_sgm3_bands(int H, int lpc, int nt) { const int slots = nt / lpc; return (H + slots - 1) / slots; }
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)md_sgm3_bands(H, lpc, nt) * W * 3 * lpc * DPL, 256); }
+size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * md_sgm3_bands(H, lpc, nt)) * sizeof(int), 256); }
+
+// Both sweeps over all bands of `batch` pairs.  `a` carries the census planes, the S volume (four-path sums: bytes when
+// s4b, else u16 in register order; with naturalOut the up sweep leaves the full sum there as u16 in natural order) and
+// the winner-take-all records; `sync` must be zero.
+int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int nt,
+                   int naturalOut, bool s4b)
+{
+    RowArgs ra;
+    ra.a = a; ra.hand = hand; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
+    ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = 0;
+    const bool tail = a.tail != 0;
+    if (nt == 512) {
+        if (lpc == 4) return launch_rows<4, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
+        if (lpc == 8) return launch_rows<8, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
+        return launch_rows<16, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
+    }
+    if (lpc == 4) return launch_rows<4, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    if (lpc == 8) return launch_rows<8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    return launch_rows<16, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+}

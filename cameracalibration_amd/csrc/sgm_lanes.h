@@ -15,6 +15,25 @@
 #pragma once
 #include "common.h"
 
+struct Sgm2Args {
+    const u8* cL; size_t pL, strideL;     // census of the left image      [B][H][pL]
+    const u8* cR; size_t pR, strideR;     // census of the padded right    [B][H][pR]
+    u16* S; size_t strideS;               // partial sums                  [B][H][W][256] (register order)
+    u16* bnd[4]; size_t strideB;          // strip-border diagonal states  [B][H][nstrips][256]
+    u8* Hvol[2]; size_t strideH;          // horizontal path volumes (1,0) and (-1,0): [B][H][W][256] u8 or u16
+    int H, W, D, minD, maxD, nstrips;
+    u32 P1P1, P2P2;
+    int tail;                             // 1 when D < 256: disparities >= D are masked off
+    int naturalOut;                       // last sweep: store the full sum in natural d order (volume export)
+    int byteSum;                          // the two byte volumes a sweep adds first (8 paths: horizontal + four-path sum; 5 paths: both horizontals) sum to a byte
+    int five;                             // 5-path mode (both horizontals + the three downward paths): the down sweep is the last one
+    u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
+    uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
+    int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
+};
+// WTA record: x = minS' | (best d << 16) | (not-unique << 31),  y = S'(best-1) | (S'(best+1) << 16)
+// order of bnd[]: 0 (1,1)  1 (-1,1)  2 (1,-1)  3 (-1,-1)
+
 namespace {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -62,24 +81,6 @@ constexpr int NR = 8;          // packed registers per lane (16 disparities)
 constexpr int DPL = 16;        // disparities per lane
 constexpr int CW = 16;         // strip width in columns
 
-struct Sgm2Args {
-    const u8* cL; size_t pL, strideL;     // census of the left image      [B][H][pL]
-    const u8* cR; size_t pR, strideR;     // census of the padded right    [B][H][pR]
-    u16* S; size_t strideS;               // partial sums                  [B][H][W][256] (register order)
-    u16* bnd[4]; size_t strideB;          // strip-border diagonal states  [B][H][nstrips][256]
-    u8* Hvol[2]; size_t strideH;          // horizontal path volumes (1,0) and (-1,0): [B][H][W][256] u8 or u16
-    int H, W, D, minD, maxD, nstrips;
-    u32 P1P1, P2P2;
-    int tail;                             // 1 when D < 256: disparities >= D are masked off
-    int naturalOut;                       // last sweep: store the full sum in natural d order (volume export)
-    int byteSum;                          // the two byte volumes a sweep adds first (8 paths: horizontal + four-path sum; 5 paths: both horizontals) sum to a byte
-    int five;                             // 5-path mode (both horizontals + the three downward paths): the down sweep is the last one
-    u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
-    uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
-    int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
-};
-// WTA record: x = minS' | (best d << 16) | (not-unique << 31),  y = S'(best-1) | (S'(best+1) << 16)
-// order of bnd[]: 0 (1,1)  1 (-1,1)  2 (1,-1)  3 (-1,-1)
 
 // masks that pin disparities >= D of this lane to "infinite"
 __device__ __forceinline__ void make_tail(int lic, int D, u32 (&tail)[NR])
@@ -154,7 +155,10 @@ __device__ __forceinline__ void sgm_step(u32 (&N)[NR], const u32 (&C)[NR], u32 P
     }
     u32 m1 = min(mn & 0xFFFFu, mn >> 16);
     m1 = row_min16<LPC>(m1);
-    const u32 mm = m1 | (m1 << 16);
+    u32 mm = m1 | (m1 << 16);
+    // opaque to the compiler: it would otherwise fold the broadcast into the subtraction as v_mad_i32_i24(m1, -0x10001, N),
+    // which issues at half the rate of a plain v_sub_u32
+    asm("" : "+v"(mm));
 #pragma unroll
     for (int r = 0; r < NR; r++) N[r] = pksub(N[r], mm);
 }
@@ -290,6 +294,27 @@ __device__ __forceinline__ void init_excl_mask(u32 (*exclMask)[NR])
         }
         exclMask[t][r] = m;
     }
+}
+
+// ---- hand-off of path states between workgroups of one launch ----
+// Every handed-off byte is written and read with agent-scope 8-byte atomics (write-through stores, cache-bypassing
+// loads); the producer drains its stores (s_waitcnt vmcnt(0)) before it raises its progress word, the consumer polls
+// that word and only then loads.  The compiler cannot move the accesses across those points: the drain is an asm
+// statement with a memory clobber, the poll loop ends in a signal fence.
+// a hand-off wait gives up after this many ticks of the 100 MHz real-time counter (4 s); it is read every 64 polls
+constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 400000000ull;
+__device__ __forceinline__ void hand_store(u8* p, const uint4& v)
+{
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (unsigned long long)v.z | ((unsigned long long)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint4 hand_load(const u8* p)
+{
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
 }  // namespace

@@ -165,13 +165,17 @@ SGM_CASES = [
 # how a single pair is scheduled: "latency" = the default for small batches (two sweeps side by side on two
 # streams + summing winner-take-all; for one pair the three paths of a sweep on three groups of waves, "latency, one
 # wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
-# with the strip width of small batches (512 lanes per workgroup) or of large ones (256)
-@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips"])
+# with the strip width of small batches (512 lanes per workgroup) or of large ones (256); "row bands" = the pipeline of
+# row bands with four paths per sweep that batches of eight-path problems take (256 or 512 compute lanes per band)
+@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands", "row bands, 512 lanes"])
 def sgm_schedule(request):
     from cameracalibration_amd import _lib
     _lib.tuning_reset()
     if request.param == "latency, one wave group":
         _lib.tuning_set(_lib.TUNE_SGM_PATH_WAVES_MAX, 0)
+    elif request.param.startswith("row bands"):
+        _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
+        _lib.tuning_set(_lib.TUNE_SGM_STRIP_LANES, 512 if "512" in request.param else 256)
     elif request.param != "latency":
         _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
         _lib.tuning_set(_lib.TUNE_SGM_PIPELINE, 1)
