@@ -76,6 +76,7 @@ def measured_issue_bound():
 
 
 def main():
+    global D, P2
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -85,11 +86,15 @@ def main():
     ap.add_argument("--paths", type=int, default=8, help="8 (the headline configuration) or 5 (StereoSGBM's default mode)")
     ap.add_argument("--disp", type=int, default=256, help="number of disparities (256 is the headline configuration; "
                                                           "other values are side measurements)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="scheduling override for side measurements, e.g. SGM_LANES16=1 or SGM_PIPELINE=1 (mdisp_tuning_set)")
+    ap.add_argument("--P2", type=int, default=P2, help="SGM penalty P2 (32 is the headline configuration; values above 247 select "
+                                                      "16-bit path states)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
-    global D
     D = args.disp
+    P2 = args.P2
 
     import torch
     import torch.distributed as dist
@@ -111,6 +116,9 @@ def main():
 
     from cameracalibration_amd import _lib, api, shard
     lib = _lib.load()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.tuning_set(getattr(_lib, "TUNE_" + k), int(v))
     # a stream of torch's own (not the legacy default stream), handed to the library: the inputs below are complete
     # before the first call because the uploads are followed by a device-wide synchronisation
     tstream = torch.cuda.Stream()

@@ -897,19 +897,29 @@ static int sgm2_mode(const md_sgm_plan& pl)
 {
     if (!fits_u8(pl)) return SGM2_PREPASS;
     if (md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) > 0) return SGM2_PREPASS;
+    if (pl.D > 256) return SGM2_ROWS;                 // 512 slots per pixel exist only as row bands
     if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
     if (pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1) return SGM2_ROWS;
     return SGM2_SHEAR;
 }
 
-// lanes per pixel: the sheared kernels run 64 / 128 / 256 disparity slots per pixel, the others always 256
+// lanes per pixel and disparities per lane: the sheared kernels run 64 / 128 / 256 disparity slots per pixel at 16
+// disparities per lane, the row-band kernels also 32 per lane (256 slots on 8 lanes, 512 on 16), the others always 16 x 16
+static bool rows_wide_lanes(const md_sgm_plan& pl)
+{
+    // measured at 256 disparities: 32 per lane on eight lanes saves a tenth of the instructions but needs 140 to 220
+    // registers per lane (two to three waves per SIMD) and runs 3 % slower than 16 per lane on sixteen lanes
+    return sgm2_mode(pl) == SGM2_ROWS && pl.D > 256;
+}
 static int lanes_per_pixel(const md_sgm_plan& pl)
 {
     const int mode = sgm2_mode(pl);
+    if (rows_wide_lanes(pl)) return pl.D > 256 ? 16 : 8;
     if ((mode != SGM2_SHEAR && mode != SGM2_ROWS) || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
-int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * DPL; }
+static int disp_per_lane(const md_sgm_plan& pl) { return rows_wide_lanes(pl) ? 32 : DPL; }
+int md_sgm2_slots(const md_sgm_plan& pl) { return lanes_per_pixel(pl) * disp_per_lane(pl); }
 
 static int shear_strips(int H, int W, int cw) { return (W + H - 1 + cw - 1) / cw; }
 static int shear_nt(const md_sgm_plan& pl, int batch)
@@ -919,39 +929,35 @@ static int shear_nt(const md_sgm_plan& pl, int batch)
     return (pl.npaths == 5 || batch <= 32) ? 512 : 256;
 }
 // sgm3.hip
+int md_sgm3_lanes(int lpc, int dpl);
 int md_sgm3_bands(int H, int lpc, int nt);
-size_t md_sgm3_hand_bytes(int H, int W, int lpc, int nt);
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt);
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
-int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int nt,
+int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b);
-static int rows_nt(const md_sgm_plan& pl, int batch)
-{
-    const int e = md_tune(MDISP_TUNE_SGM_STRIP_LANES);
-    if (e >= 0) return e == 512 ? 512 : 256;
-    return 256;
-}
 
 static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
 static size_t shear_sync_bytes(int H, int W, int batch, int lpc, int nt)
 { return md_align((16 + 2 * (size_t)batch * shear_strips(H, W, nt / lpc)) * sizeof(int), 256); }
 
-struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, slots, mode, cw; bool u8m; };
+struct Sgm2Layout { size_t oneB, bndBytes, oneH, oneRec, oneS2, syncBytes; int nstrips, lpc, dpl, slots, mode, cw; bool u8m; };
 static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
 {
     Sgm2Layout l;
     l.u8m = fits_u8(pl);
     l.mode = sgm2_mode(pl);
     l.lpc = lanes_per_pixel(pl);
-    l.slots = l.lpc * DPL;
+    l.dpl = disp_per_lane(pl);
+    l.slots = l.lpc * l.dpl;
     l.cw = CW;
     l.nstrips = (pl.W + l.cw - 1) / l.cw;
     if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // hand-off rows (sized for the narrower strips)
-    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // last-row states of every band (sized for the lower bands)
+    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl)); }   // last-row states of every band
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = l.mode == SGM2_ROWS ? 0 : md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
     l.oneS2 = l.mode == SGM2_SPLIT ? md_align((size_t)pl.H * pl.W * 256 * sizeof(u16), 256) : 0;
-    l.syncBytes = l.mode == SGM2_ROWS ? md_sgm3_sync_bytes(pl.H, batch, l.lpc, 256) : shear_sync_bytes(pl.H, pl.W, batch, l.lpc, 256);
+    l.syncBytes = l.mode == SGM2_ROWS ? md_sgm3_sync_bytes(pl.H, batch, l.lpc, md_sgm3_lanes(l.lpc, l.dpl)) : shear_sync_bytes(pl.H, pl.W, batch, l.lpc, 256);
     return l;
 }
 
@@ -963,7 +969,7 @@ size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
 {
-    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && pl.D <= 256 && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
+    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && (pl.D <= 256 || (pl.npaths == 8 && fits_u8(pl))) && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 
@@ -1077,7 +1083,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
         }
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, rows_nt(pl, batch), naturalOut, s4b));
+        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), naturalOut, s4b));
     } else if (l.mode == SGM2_SHEAR) {
         ShearArgs sa;
         sa.a = a;

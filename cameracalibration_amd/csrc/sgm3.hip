@@ -23,13 +23,13 @@
 // b before band b+1), so a workgroup only waits for one that started earlier; an extra "communication" wave per
 // workgroup does the exchange (agent-scope write-through stores, drain, then the progress word; agent-scope loads on
 // the consumer side, parked in LDS one step ahead); every wait is bounded and reports through a sticky error word.
-#include "sgm_lanes.h"
+#include "sgm_lanes_n.h"
 
 namespace {
 
 struct RowArgs {
     Sgm2Args a;
-    u8* hand;               // [B][nb][W][3][LPC*16] bytes: states (v, \, /) of the last row of every band, per pixel
+    u8* hand;               // [B][nb][W][3][slots bytes]: states (v, \, /) of the last row of every band, per pixel
     size_t strideHand;      // bytes per pair
     int* sync;              // [0] ticket (down) [1] ticket (up), [16 + (sweep*B + pair)*nb + band] pixels published by the band's last row
     int* err;               // sticky error word (owned by the caller)
@@ -37,18 +37,22 @@ struct RowArgs {
     int band0;              // first band this launch runs (its predecessor's states and progress word are already in place)
 };
 
-template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, int NT>
+// LPC lanes share a pixel, each with NRT packed registers (2 NRT disparities); NT compute lanes per workgroup.
+// Byte images of a pixel (LDS states, hand-off rows, byte four-path sums) are stored as NRT/8 planes of LPC*16 bytes:
+// plane p holds dwords 4p .. 4p+3 of every lane's packed state, so that one 16-byte access per lane is contiguous
+// across the pixel's lanes.
+template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, int NRT, int NT>
 __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
 {
-    constexpr int SLOTS = NT / LPC, DP = LPC * DPL, SW = LPC * 4;
+    constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, SW = PL * PW, NW = NRT / 2;
     const Sgm2Args& a = ra.a;
-    __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][bytes of the pixel's LPC lanes]
+    __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][packed bytes of the pixel]
     __shared__ u32 hin[2][3][SW];           // the band above's states for slot 0, same parity rule
-    __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * 8 : 1];
-    __shared__ u32 exclMask[FUSE ? 19 : 1][NR];
+    __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * NRT : 1];
+    __shared__ u32 exclMask[FUSE ? DPLn + 3 : 1][NRT];
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[UP ? 1 : 0], 1);
-    if (FUSE) init_excl_mask(exclMask);
+    if (FUSE) init_excl_mask_n<NRT>(exclMask);
     __syncthreads();
     const int ticket = s_ticket;
     const int ord = ticket / ra.batch, pair = ticket - ord * ra.batch;
@@ -57,6 +61,17 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
     const int T = W + 2 * (SLOTS - 1);                    // steps: slot j works on u = t - 2j
     u8* hand = ra.hand + (size_t)pair * ra.strideHand;
     const bool hasPrev = band > 0, hasNext = band + 1 < ra.nb;
+    auto lds_get = [&](const u32* p, u32 (&w)[NW]) {       // p: the lane's first dword of plane 0
+#pragma unroll
+        for (int q = 0; q < PL; q++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + q * PW);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    };
+    auto lds_put = [&](u32* p, const u32 (&w)[NW]) {
+#pragma unroll
+        for (int q = 0; q < PL; q++) *reinterpret_cast<uint4*>(p + q * PW) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    };
 
     if (threadIdx.x >= NT) {
         // ---- communication wave: publishes the last slot's states one step behind the compute waves and fetches
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
         auto hand_slot = [&](int bnd, int u, int wh) -> u8* { return hand + ((((size_t)bnd * W + u) * 3 + wh) * DP + lic * 16); };
         // slot 0 consumes in step i (i >= -1) the states of pixel i + 1 of the row above
         auto wants = [&](int i) -> bool { return hasPrev && which < 3 && i + 1 < W; };
-        auto request = [&](int i, uint4& w) {
+        auto request = [&](int i, u32 (&w)[NW]) {
             const bool mine = wants(i);
             if (!__any(mine)) return;
             const int need = i + 2;                       // pixels the band above must have published
@@ -93,15 +108,26 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
-            if (mine) w = hand_load(hand_slot(band - 1, i + 1, which));
+            if (mine) {
+                const u8* src = hand_slot(band - 1, i + 1, which);
+#pragma unroll
+                for (int q = 0; q < PL; q++) {
+                    const uint4 v = hand_load(src + q * LPC * 16);
+                    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+                }
+            }
         };
-        auto park = [&](int i, const uint4& w) {          // hand the fetched states of step i to slot 0
-            if (wants(i)) *reinterpret_cast<uint4*>(&hin[(i + 1) & 1][which][lic * 4]) = w;
+        auto park = [&](int i, const u32 (&w)[NW]) {      // hand the fetched states of step i to slot 0
+            if (wants(i)) lds_put(&hin[(i + 1) & 1][which][lic * 4], w);
         };
         auto send = [&](int t) {                           // step t has been computed: the last slot's states are in st[t & 1]
             const int u = t - 2 * (SLOTS - 1);
-            if (hasNext && which < 3 && u >= 0 && u < W)
-                hand_store(hand_slot(band, u, which), *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][lic * 4]));
+            if (hasNext && which < 3 && u >= 0 && u < W) {
+                u8* dst = hand_slot(band, u, which);
+#pragma unroll
+                for (int q = 0; q < PL; q++)
+                    hand_store(dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][q * PW + lic * 4]));
+            }
         };
         auto announce = [&](int t) {                       // the states of steps up to t are in memory
             const int u = t - 2 * (SLOTS - 1);
@@ -110,7 +136,9 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
         // Software pipeline, one step per pixel, that never waits for an operation issued in the same step: step t first
         // drains what step t-1 issued (stores of step t-2's states, loads for step t+1, a sample of the neighbour's
         // progress), then announces step t-2, sends step t-1, parks step t+1's states in LDS and requests step t+2's.
-        uint4 w = make_uint4(0, 0, 0, 0);
+        u32 w[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) w[q] = 0;
         request(-1, w);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         park(-1, w);
@@ -145,21 +173,21 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
     const int y = UP ? H - 1 - vc : vc;
     const bool top = v == 0;
     const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
-    const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR + (a.maxD - a.minD - lic * DPL - 15);
-    u8* Srow = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)y * W * (S4B ? DP : 2 * DP) + lic * (S4B ? 16 : 32);
+    const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR + (a.maxD - a.minD - lic * DPLn - (DPLn - 1));
+    u8* Srow = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)y * W * (S4B ? DP : 2 * DP) + lic * 16;
     const size_t recRow = (size_t)pair * a.strideRec + (size_t)y * W;
-    u32 tail[NR];
-    make_tail(lic, a.D, tail);
+    u32 tail[NRT];
+    make_tail_n<NRT>(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
-    auto fresh = [&](u32 (&N)[NR]) {
+    auto fresh = [&](u32 (&N)[NRT]) {
 #pragma unroll
-        for (int q = 0; q < NR; q++) N[q] = TAIL ? tail[q] : 0u;
+        for (int q = 0; q < NRT; q++) N[q] = TAIL ? tail[q] : 0u;
     };
-    auto from_bytes = [&](const uint4& w, u32 (&N)[NR]) {     // all-zero bytes are the state of a path that starts here
-        unpack_bytes(w, N);
+    auto from_bytes = [&](const u32 (&w)[NW], u32 (&N)[NRT]) {     // all-zero bytes are the state of a path that starts here
+        unpack_n<NRT>(w, N);
         if (TAIL) {
 #pragma unroll
-            for (int q = 0; q < NR; q++) N[q] |= tail[q];
+            for (int q = 0; q < NRT; q++) N[q] |= tail[q];
         }
     };
     // where this slot reads the row above's states: slot j-1's LDS entry, or (slot 0) what the communication wave parked;
@@ -167,97 +195,125 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
     const u32* aboveBase = j > 0 ? &st[0][j - 1][0][lic * 4] : &hin[0][0][lic * 4];
     const int aboveStride = j > 0 ? SLOTS * 3 * SW : 3 * SW;
 
-    u32 Nh[NR];                        // the path that runs along the row
+    u32 Nh[NRT];                       // the path that runs along the row
     fresh(Nh);
-    u32 clw = 0; uint4 rb = make_uint4(0, 0, 0, 0), sb = make_uint4(0, 0, 0, 0);
-    u32 Sn[NR];
-    zero8(Sn);
+    u32 clw = 0, rbw[NW], sbw[NW], Sn[NRT];
+#pragma unroll
+    for (int q = 0; q < NW; q++) { rbw[q] = 0; sbw[q] = 0; }
+#pragma unroll
+    for (int q = 0; q < NRT; q++) Sn[q] = 0;
     int xf = 0;                        // the column the operands in flight belong to
     auto fetch = [&](int t) {          // unconditional: out-of-range steps ask for the nearest pixel of the row again
         const int u = min(max(t - 2 * j, 0), W - 1);
         xf = UP ? W - 1 - u : u;
         clw = *reinterpret_cast<const u32*>(cLrow + (xf & ~3));
-        __builtin_memcpy(&rb, cRrow + xf, 16);
+        __builtin_memcpy(rbw, cRrow + xf, 2 * NRT);
         if (UP) {
-            if (S4B) sb = load16_stream(Srow + (size_t)xf * DP);
-            else load8_stream(reinterpret_cast<const u16*>(Srow + (size_t)xf * 2 * DP), Sn);
+            if (S4B) {
+#pragma unroll
+                for (int q = 0; q < PL; q++) {
+                    const uint4 v4 = load16_stream(Srow + (size_t)xf * DP + q * LPC * 16);
+                    sbw[4 * q] = v4.x; sbw[4 * q + 1] = v4.y; sbw[4 * q + 2] = v4.z; sbw[4 * q + 3] = v4.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NRT / 4; q++) {
+                    const uint4 v4 = load16_stream(Srow + (size_t)xf * 2 * DP + q * LPC * 16);
+                    Sn[4 * q] = v4.x; Sn[4 * q + 1] = v4.y; Sn[4 * q + 2] = v4.z; Sn[4 * q + 3] = v4.w;
+                }
+            }
         }
     };
     fetch(0);
     // states of the row above kept in registers: the vertical one for one step, the diagonal one for two.  The loop is
     // unrolled by two so that "keep" is a matter of which register set a step names, not of copies.
-    uint4 V0 = make_uint4(0, 0, 0, 0), V1 = V0, DA = V0, DB = V0;
+    u32 V0[NW], V1[NW], DA[NW], DB[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; }
     __syncthreads();                   // the communication wave has parked pixel 0 and pixel 1 of the row above
     if (j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
-        V0 = *reinterpret_cast<const uint4*>(&hin[0][0][lic * 4]);
-        DB = *reinterpret_cast<const uint4*>(&hin[0][1][lic * 4]);
+        lds_get(&hin[0][0][lic * 4], V0);
+        lds_get(&hin[0][1][lic * 4], DB);
     }
     __syncthreads();
     // one step: Vuse was read in the previous step, D two steps ago; Vfill / D receive what the row above published in
     // the previous step (D only after its old contents have been consumed)
-    auto step = [&](int t, uint4& Vuse, uint4& Vfill, uint4& D) {
+    auto step = [&](int t, u32 (&Vuse)[NW], u32 (&Vfill)[NW], u32 (&D)[NW]) {
         const int u = t - 2 * j;
         const bool active = rowOk && u >= 0 && u < W;
         const int x = xf;
-        u32 C[NR], L[NR], Sacc[NR];
-        cost_from_operands(census_byte(clw, x), rb, C);
+        u32 C[NRT], L[NRT], Sacc[NRT];
+        cost_n<NRT>(census_byte(clw, x), rbw, C);
         if (UP) {
-            if (S4B) unpack_bytes(sb, Sacc);
+            if (S4B) unpack_n<NRT>(sbw, Sacc);
             else {
 #pragma unroll
-                for (int q = 0; q < NR; q++) Sacc[q] = Sn[q];
+                for (int q = 0; q < NRT; q++) Sacc[q] = Sn[q];
             }
         }
         fetch(t + 1);
         const u32* above = aboveBase + ((t + 1) & 1) * aboveStride;
-        Vfill = *reinterpret_cast<const uint4*>(above);
-        uint4 curA = *reinterpret_cast<const uint4*>(above + 2 * SW);      // anti-diagonal: used at once
+        lds_get(above, Vfill);
+        u32 curA[NW];
+        lds_get(above + 2 * SW, curA);                  // anti-diagonal: used at once
         if (active) {
             // paths that start at this pixel (image border): rare, so the per-lane selects sit behind a wave-level test
             const bool firstCol = u == 0, lastCol = u == W - 1;
             if (__any(top || firstCol || lastCol)) {
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                if (top || lastCol) curA = z;
-                if (top) Vuse = z;
-                if (top || firstCol) D = z;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    if (top || lastCol) curA[q] = 0;
+                    if (top) Vuse[q] = 0;
+                    if (top || firstCol) D[q] = 0;
+                }
                 if (firstCol) fresh(Nh);
             }
-            sgm_step<TAIL, LPC>(Nh, C, P1P1, P2P2, tail, L, lic);
+            step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic);
 #pragma unroll
-            for (int q = 0; q < NR; q++) Sacc[q] = UP ? pkadd(Sacc[q], L[q]) : L[q];
-            u32 N[NR];
+            for (int q = 0; q < NRT; q++) Sacc[q] = UP ? pkadd(Sacc[q], L[q]) : L[q];
+            u32 N[NRT], ow[NW];
             from_bytes(curA, N);
-            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
 #pragma unroll
-            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            *reinterpret_cast<uint4*>(&st[t & 1][j][2][lic * 4]) = pack_bytes(N);
+            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            lds_put(&st[t & 1][j][2][lic * 4], ow);
             from_bytes(Vuse, N);
-            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
 #pragma unroll
-            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            *reinterpret_cast<uint4*>(&st[t & 1][j][0][lic * 4]) = pack_bytes(N);
+            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            lds_put(&st[t & 1][j][0][lic * 4], ow);
             from_bytes(D, N);
-            sgm_step<TAIL, LPC>(N, C, P1P1, P2P2, tail, L, lic);
+            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
 #pragma unroll
-            for (int q = 0; q < NR; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            *reinterpret_cast<uint4*>(&st[t & 1][j][1][lic * 4]) = pack_bytes(N);
+            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+            lds_put(&st[t & 1][j][1][lic * 4], ow);
             if (!UP) {
-                if (S4B) store16_stream(Srow + (size_t)x * DP, pack_bytes(Sacc));
-                else store8_stream(reinterpret_cast<u16*>(Srow + (size_t)x * 2 * DP), Sacc);
+                if (S4B) {
+                    pack_n<NRT>(Sacc, ow);
+#pragma unroll
+                    for (int q = 0; q < PL; q++)
+                        store16_stream(Srow + (size_t)x * DP + q * LPC * 16, make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NRT / 4; q++)
+                        store16_stream(Srow + (size_t)x * 2 * DP + q * LPC * 16, make_uint4(Sacc[4 * q], Sacc[4 * q + 1], Sacc[4 * q + 2], Sacc[4 * q + 3]));
+                }
             } else if (FUSE) {
-                fused_wta<TAIL, LPC>(a, Sacc, tail, lic, &srow[j][0], exclMask, recRow + x);
+                wta_n<TAIL, LPC, NRT>(a, Sacc, tail, lic, &srow[j][0], exclMask, recRow + x);
             } else {
                 // volume export: the full sum in natural disparity order, in place of the four-path sum
-                u32 nat[NR];
+                u32 nat[NRT];
 #pragma unroll
-                for (int g = 0; g < NR / 2; g++) {
+                for (int g = 0; g < NRT / 2; g++) {
                     nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
-                    nat[g + 4] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+                    nat[g + NRT / 2] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
-                store8(reinterpret_cast<u16*>(Srow + (size_t)x * 2 * DP), nat);
+                uint4* dst = reinterpret_cast<uint4*>(Srow - lic * 16 + (size_t)x * 2 * DP + lic * DPLn * 2);
+#pragma unroll
+                for (int q = 0; q < NRT / 4; q++) dst[q] = make_uint4(nat[4 * q], nat[4 * q + 1], nat[4 * q + 2], nat[4 * q + 3]);
             }
         }
-        D = *reinterpret_cast<const uint4*>(above + SW);
+        lds_get(above + SW, D);
         __syncthreads();   // st[t & 1] complete before the next step reads it
     };
     int t = 0;
@@ -268,15 +324,15 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
     if (t < T) step(t, V0, V1, DA);
 }
 
-template <int LPC, int NT>
+template <int LPC, int NRT, int NT>
 int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, int naturalOut, bool s4b, bool tail)
 {
     const dim3 g((unsigned)nbands * ra.batch);
-#define SGM3_LAUNCH(TAILV, S4BV)                                                                         \
-    do {                                                                                                 \
-        sgm3_rows_kernel<false, TAILV, false, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);                  \
-        if (naturalOut) sgm3_rows_kernel<true, TAILV, false, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);   \
-        else sgm3_rows_kernel<true, TAILV, true, S4BV, LPC, NT><<<g, NT + 64, 0, s>>>(ra);               \
+#define SGM3_LAUNCH(TAILV, S4BV)                                                                              \
+    do {                                                                                                      \
+        sgm3_rows_kernel<false, TAILV, false, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);                  \
+        if (naturalOut) sgm3_rows_kernel<true, TAILV, false, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);   \
+        else sgm3_rows_kernel<true, TAILV, true, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);               \
     } while (0)
     if (tail) { if (s4b) SGM3_LAUNCH(true, true); else SGM3_LAUNCH(true, false); }
     else { if (s4b) SGM3_LAUNCH(false, true); else SGM3_LAUNCH(false, false); }
@@ -287,26 +343,29 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, int naturalOut, bo
 
 }  // namespace
 
-int md_sgm3_bands(int H, int lpc, int nt) { const int slots = nt / lpc; return (H + slots - 1) / slots; }
-size_t md_sgm3_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)md_sgm3_bands(H, lpc, nt) * W * 3 * lpc * DPL, 256); }
+// geometry of the row-band kernels: a pixel has lpc lanes x dpl disparity slots; compute lanes per workgroup (512 slots
+// per pixel: eight rows per band, so that the states and the winner-take-all rows of a band fit the 64 KB of static LDS)
+int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : 256; }
+int md_sgm3_bands(int H, int lpc, int nt) { const int rows = nt / lpc; return (H + rows - 1) / rows; }
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt) { return md_align((size_t)md_sgm3_bands(H, lpc, nt) * W * 3 * lpc * dpl, 256); }
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * md_sgm3_bands(H, lpc, nt)) * sizeof(int), 256); }
 
 // Both sweeps over all bands of `batch` pairs.  `a` carries the census planes, the S volume (four-path sums: bytes when
 // s4b, else u16 in register order; with naturalOut the up sweep leaves the full sum there as u16 in natural order) and
 // the winner-take-all records; `sync` must be zero.
-int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int nt,
+int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b)
 {
     RowArgs ra;
     ra.a = a; ra.hand = hand; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
     ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = 0;
     const bool tail = a.tail != 0;
-    if (nt == 512) {
-        if (lpc == 4) return launch_rows<4, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
-        if (lpc == 8) return launch_rows<8, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
-        return launch_rows<16, 512>(s, ra, ra.nb, naturalOut, s4b, tail);
+    MD_REQUIRE(nt == md_sgm3_lanes(lpc, dpl) && (dpl == 16 || dpl == 32), MDISP_E_BADARG, "row bands: unsupported geometry");
+    if (dpl == 32) {
+        if (lpc == 16) return launch_rows<16, 16, 128>(s, ra, ra.nb, naturalOut, s4b, tail);
+        MD_REQUIRE(false, MDISP_E_BADARG, "row bands: unsupported geometry");
     }
-    if (lpc == 4) return launch_rows<4, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
-    if (lpc == 8) return launch_rows<8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
-    return launch_rows<16, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    if (lpc == 4) return launch_rows<4, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    if (lpc == 8) return launch_rows<8, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    return launch_rows<16, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
 }

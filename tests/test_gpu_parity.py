@@ -159,6 +159,11 @@ SGM_CASES = [
     (50, 120, 0, 64, 8, 200, 10, 1, 5, 1),      # five paths, byte path values whose pairwise sums exceed a byte
     (50, 120, 0, 64, 8, 44, 10, 1, 8, 1),       # eight paths: byte four-path sums, but horizontal + sum exceeds a byte
     (50, 120, 0, 64, 8, 43, 10, 1, 8, 1),       # ... and the largest P2 for which it does not
+    (40, 700, 0, 512, 8, 32, 10, 1, 8, 1),      # 512 disparities: sixteen lanes x 32 per lane, row bands of eight rows
+    (37, 420, 3, 300, 6, 60, 10, 2, 8, 1),      # ... with a masked tail and 16-bit four-path sums
+    (30, 350, 0, 257, 8, 247, 10, 1, 8, 0),     # ... just above 256, largest P2 with byte path states
+    (45, 300, 0, 200, 8, 32, 10, 1, 8, 1),      # sixteen lanes with a masked tail
+    (45, 300, 0, 129, 8, 100, 10, 1, 8, 1),     # ... just above 128, 16-bit four-path sums
 ]
 
 
@@ -166,8 +171,8 @@ SGM_CASES = [
 # streams + summing winner-take-all; for one pair the three paths of a sweep on three groups of waves, "latency, one
 # wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
 # with the strip width of small batches (512 lanes per workgroup) or of large ones (256); "row bands" = the pipeline of
-# row bands with four paths per sweep that batches of eight-path problems take (256 or 512 compute lanes per band)
-@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands", "row bands, 512 lanes"])
+# row bands with four paths per sweep that batches of eight-path problems take
+@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands"])
 def sgm_schedule(request):
     from cameracalibration_amd import _lib
     _lib.tuning_reset()
@@ -175,7 +180,6 @@ def sgm_schedule(request):
         _lib.tuning_set(_lib.TUNE_SGM_PATH_WAVES_MAX, 0)
     elif request.param.startswith("row bands"):
         _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
-        _lib.tuning_set(_lib.TUNE_SGM_STRIP_LANES, 512 if "512" in request.param else 256)
     elif request.param != "latency":
         _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
         _lib.tuning_set(_lib.TUNE_SGM_PIPELINE, 1)
@@ -272,9 +276,10 @@ def test_sgm_batch_matches_single_calls(api, orc, B):
         assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], 0, D, 8, 32, 10, 1, 8, 1))
 
 
-def test_sgm_volume_bit_exact(api, orc):
+def test_sgm_volume_bit_exact(api, orc, sgm_schedule):
     for (H, W, minD, D, P1, P2) in [(24, 40, 0, 16, 8, 32), (37, 53, 0, 64, 8, 32), (16, 130, 0, 256, 8, 32),
-                                    (40, 70, 3, 200, 5, 30), (33, 17, 0, 256, 8, 32), (29, 45, 0, 96, 20, 300)]:
+                                    (40, 70, 3, 200, 5, 30), (33, 17, 0, 256, 8, 32), (29, 45, 0, 96, 20, 300),
+                                    (21, 90, 0, 512, 8, 32), (18, 75, 1, 400, 8, 100)]:
         L, R = rand_pair(H * 31 + W, H, W, min(D, W))
         S = api.sgbm_volume(L, R, api.sgbm_params(minD, D, P1, P2, 10, 1, 8, 1))
         _, E = orc.sgm(L, R, minD, D, P1, P2, 10, 1, 8, 1, want_S=True)
