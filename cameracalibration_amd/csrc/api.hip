@@ -1058,7 +1058,7 @@ extern "C" int mdisp_sgbm_volume(mdisp_ctx* c, const mdisp_image* L, const mdisp
     if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
     MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
     md_sgm_plan pl;
-    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, 1, &pl))) return rc;
+    if ((rc = md_sgm_plan_make(L->rows, L->cols, p, 1, &pl, true))) return rc;
     MD_HIP(hipSetDevice(c->device));
     const int H = L->rows, W = L->cols;
     const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);

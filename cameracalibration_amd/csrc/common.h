@@ -102,10 +102,11 @@ bool md_sgm2_supported(const md_sgm_plan& pl);
 size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch);
 int md_sgm2_slots(const md_sgm_plan& pl);   // u16 elements per pixel of the S volume (64, 128 or 256)
 bool md_sgm2_u8(const md_sgm_plan& pl);
+size_t md_sgm2_partial_sum_bytes(const md_sgm_plan& pl);   // bytes per slot of the volume between the sweeps when winner-take-all is fused (1 or 2)
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
                       u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
                       const md_aux_streams* aux = nullptr);
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan);
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume = false);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
                int16_t* dDisp, void* ws);
 // aggregation only; *S receives the device volume (pixel stride plan.sstride)

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
 
 static const int DIRS[8][2] = {{+1, 0}, {-1, 0}, {0, +1}, {0, -1}, {+1, +1}, {-1, +1}, {+1, -1}, {-1, -1}};
 
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan)
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume)
 {
     MD_REQUIRE(batch >= 1 && batch <= 4096, MDISP_E_BADARG, "batch must be in 1..4096");
     plan->batch = batch;
@@ -278,7 +278,10 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm
     off = md_align(off, 256);
     plan->use_v2 = md_sgm2_supported(*plan) && md_tune(MDISP_TUNE_SGM_PER_DIRECTION) <= 0;
     plan->sstride = plan->use_v2 ? md_sgm2_slots(*plan) : plan->D;
-    plan->strideS = md_align((size_t)H * W * plan->sstride * sizeof(u16), 256) / sizeof(u16);
+    // the volume between the two sweeps: one byte per slot where the schedule's four-path sums fit a byte (and the
+    // caller does not want the full 16-bit sums exported), else 16 bits
+    const size_t slotBytes = plan->use_v2 && !exportVolume ? md_sgm2_partial_sum_bytes(*plan) : sizeof(u16);
+    plan->strideS = md_align((size_t)H * W * plan->sstride * slotBytes, 256) / sizeof(u16);
     plan->off_S = off; off += plan->strideS * sizeof(u16) * batch;
     off = md_align(off, 256);
     plan->off_aux = off; off += 4096;

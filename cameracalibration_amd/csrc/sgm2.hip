@@ -974,6 +974,12 @@ bool md_sgm2_supported(const md_sgm_plan& pl)
 }
 
 bool md_sgm2_u8(const md_sgm_plan& pl) { return fits_u8(pl); }
+size_t md_sgm2_partial_sum_bytes(const md_sgm_plan& pl)
+{
+    const int mode = sgm2_mode(pl);
+    const bool byteSums = 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+    return (mode == SGM2_ROWS || (mode == SGM2_SHEAR && pl.npaths == 8)) && byteSums ? 1 : 2;
+}
 
 namespace {
 template <int LPC, int NT>

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
         const int* progNb = progMe - 1;
         int* errWord = ra.err;
         int seen = 0;
-        auto hand_slot = [&](int bnd, int u, int wh) -> u8* { return hand + ((((size_t)bnd * W + u) * 3 + wh) * DP + lic * 16); };
+        const __amdgpu_buffer_rsrc_t rsrc = hand_rsrc(hand, ra.strideHand);      // the pair's rows: below 4 GB
+        auto hand_slot = [&](int bnd, int u, int wh) -> u32 { return (u32)((((size_t)bnd * W + u) * 3 + wh) * DP + lic * 16); };
         // slot 0 consumes in step i (i >= -1) the states of pixel i + 1 of the row above
         auto wants = [&](int i) -> bool { return hasPrev && which < 3 && i + 1 < W; };
         auto request = [&](int i, u32 (&w)[NW]) {
@@ -109,10 +110,10 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }
             if (mine) {
-                const u8* src = hand_slot(band - 1, i + 1, which);
+                const u32 src = hand_slot(band - 1, i + 1, which);
 #pragma unroll
                 for (int q = 0; q < PL; q++) {
-                    const uint4 v = hand_load(src + q * LPC * 16);
+                    const uint4 v = hand_load16(rsrc, src + q * LPC * 16);
                     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
                 }
             }
@@ -123,10 +124,10 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
         auto send = [&](int t) {                           // step t has been computed: the last slot's states are in st[t & 1]
             const int u = t - 2 * (SLOTS - 1);
             if (hasNext && which < 3 && u >= 0 && u < W) {
-                u8* dst = hand_slot(band, u, which);
+                const u32 dst = hand_slot(band, u, which);
 #pragma unroll
                 for (int q = 0; q < PL; q++)
-                    hand_store(dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][q * PW + lic * 4]));
+                    hand_store16(rsrc, dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][q * PW + lic * 4]));
             }
         };
         auto announce = [&](int t) {                       // the states of steps up to t are in memory

@@ -317,4 +317,23 @@ __device__ __forceinline__ uint4 hand_load(const u8* p)
     return make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
 }
 
+// The same hand-off with ONE 16-byte write-through store / cache-bypassing load per lane (buffer instructions with the
+// sc1 bit; `rsrc` describes the pair's hand-off rows, `off` is the byte offset inside them): half the memory
+// instructions and fabric writes of the two 8-byte atomics above.
+typedef u32 md_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t hand_rsrc(u8* base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void hand_store16(__amdgpu_buffer_rsrc_t rsrc, u32 off, const uint4& v)
+{
+    md_v4u d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)off, 0, 16);
+}
+__device__ __forceinline__ uint4 hand_load16(__amdgpu_buffer_rsrc_t rsrc, u32 off)
+{
+    const md_v4u d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 16);
+    return make_uint4(d.x, d.y, d.z, d.w);
+}
+
 }  // namespace
