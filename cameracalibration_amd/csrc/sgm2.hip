@@ -1039,6 +1039,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.rec = (uint2*)(hbase + 2 * l.oneH * batch);
     a.strideRec = l.oneRec / sizeof(uint2);
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
+    a.smallS = ((long)pl.npaths * (8 * pl.costWin * pl.costWin + pl.P2) + 1) * l.dpl < 0x7C00;
     a.S2 = nullptr; a.splitUp = 0;
     u8* afterRec = hbase + 2 * l.oneH * batch + l.oneRec * batch;
     if (l.mode == SGM2_SPLIT && !naturalOut && strideS * sizeof(u16) == l.oneS2) {

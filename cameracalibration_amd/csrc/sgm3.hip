@@ -42,7 +42,7 @@ struct RowArgs {
 // plane p holds dwords 4p .. 4p+3 of every lane's packed state, so that one 16-byte access per lane is contiguous
 // across the pixel's lanes.
 template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, int NRT, int NT>
-__global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
+__global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
 {
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, SW = PL * PW, NW = NRT / 2;
     const Sgm2Args& a = ra.a;
@@ -105,7 +105,11 @@ __global__ __launch_bounds__(NT + 64) void sgm3_rows_kernel(RowArgs ra)
                         seen = 0x7FFFFFFF;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
+                    // back off: a band that waits for its predecessor's head start waits for tens of steps, and every
+                    // poll is a memory-side access next to the streams of the working bands
+                    if (it < 4) __builtin_amdgcn_s_sleep(2);
+                    else if (it < 16) __builtin_amdgcn_s_sleep(16);
+                    else __builtin_amdgcn_s_sleep(64);
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
             }

@@ -30,6 +30,7 @@ struct Sgm2Args {
     u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
     uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
     int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
+    int smallS;                           // every aggregated cost, times the disparities per lane, stays below 0x7C00 (row-band winner-take-all)
 };
 // WTA record: x = minS' | (best d << 16) | (not-unique << 31),  y = S'(best-1) | (S'(best+1) << 16)
 // order of bnd[]: 0 (1,1)  1 (-1,1)  2 (1,-1)  3 (-1,-1)

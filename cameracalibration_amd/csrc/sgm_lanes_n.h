@@ -146,13 +146,27 @@ __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT],
                                       const u32 (*exclMask)[NRT], size_t recIndex)
 {
     constexpr int DPLn = 2 * NRT, SH = NRT == 8 ? 4 : 5;
-    u32 kmin = 0xFFFFFFFFu;
+    // keys (S * DPL + local index) as packed pairs; while every key stays below 0x7C00 (a.smallS) their minimum is a
+    // tree of packed three-input minima, and "excluded" is the bit pattern 0x7000 instead of 0xFFFF
+    const bool small = !TAIL && a.smallS != 0;       // (masked disparities are OR-ed out, which could leave the ordered range)
+    const u32 OUT1 = small ? 0x7000u : 0xFFFFu;
+    u32 k[NRT];
 #pragma unroll
     for (int q = 0; q < NRT; q++) {
         const u32 idx = (u32)q | ((u32)(q + NRT) << 16);
-        u32 k = asu(asv(Sacc[q]) * (unsigned short)DPLn + asv(idx));
-        if (TAIL) k |= (tail[q] & 0x0000FFFFu ? 0x0000FFFFu : 0u) | (tail[q] & 0xFFFF0000u ? 0xFFFF0000u : 0u);
-        kmin = q == 0 ? k : pkmin(kmin, k);
+        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(k[q]) : "v"(Sacc[q]), "v"((u32)DPLn | ((u32)DPLn << 16)), "v"(idx));
+        if (TAIL) k[q] |= (tail[q] & 0x0000FFFFu ? OUT1 : 0u) | (tail[q] & 0xFFFF0000u ? OUT1 << 16 : 0u);
+    }
+    u32 kmin;
+    if (small) {
+        kmin = k[0];
+#pragma unroll
+        for (int q = 1; q + 1 < NRT; q += 2) kmin = pkmin3(kmin, k[q], k[q + 1]);
+        kmin = pkmin(kmin, k[NRT - 1]);
+    } else {
+        kmin = k[0];
+#pragma unroll
+        for (int q = 1; q < NRT; q++) kmin = pkmin(kmin, k[q]);
     }
     const u32 kl = min(kmin & 0xFFFFu, kmin >> 16);
     u32 key = ((kl >> SH) << 16) | (u32)(lic * DPLn) | (kl & (u32)(DPLn - 1));
@@ -161,16 +175,27 @@ __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT],
     const int minS = (int)(key >> 16);
     const int rel = best - lic * DPLn;
     const int tsel = (unsigned)(rel + 1) <= (unsigned)(DPLn + 1) ? rel + 1 : DPLn + 2;
-    u32 smin = 0xFFFFFFFFu;
+    const u32 OUT2 = OUT1 | (OUT1 << 16);
+    u32 v[NRT];
 #pragma unroll
     for (int q = 0; q < NRT; q++) {
-        u32 v = Sacc[q] | exclMask[tsel][q];
-        if (TAIL) v |= (tail[q] & 0x0000FFFFu ? 0x0000FFFFu : 0u) | (tail[q] & 0xFFFF0000u ? 0xFFFF0000u : 0u);
-        smin = q == 0 ? v : pkmin(smin, v);
+        v[q] = Sacc[q] | (exclMask[tsel][q] & OUT2);
+        if (TAIL) v[q] |= (tail[q] & 0x0000FFFFu ? OUT1 : 0u) | (tail[q] & 0xFFFF0000u ? OUT1 << 16 : 0u);
+    }
+    u32 smin;
+    if (small) {
+        smin = v[0];
+#pragma unroll
+        for (int q = 1; q + 1 < NRT; q += 2) smin = pkmin3(smin, v[q], v[q + 1]);
+        smin = pkmin(smin, v[NRT - 1]);
+    } else {
+        smin = v[0];
+#pragma unroll
+        for (int q = 1; q < NRT; q++) smin = pkmin(smin, v[q]);
     }
     const int mex = (int)row_min16<LPC>(min(smin & 0xFFFFu, smin >> 16));
     // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
-    const bool notUnique = mex != 0xFFFF && __mul24(mex - a.bias, 100 - a.uniq) < __mul24(minS - a.bias, 100);
+    const bool notUnique = mex < (int)OUT1 && __mul24(mex - a.bias, 100 - a.uniq) < __mul24(minS - a.bias, 100);
 #pragma unroll
     for (int q = 0; q < NRT; q += 4)
         *reinterpret_cast<uint4*>(&srow[(q / 4) * LPC * 4 + lic * 4]) = make_uint4(Sacc[q], Sacc[q + 1], Sacc[q + 2], Sacc[q + 3]);
