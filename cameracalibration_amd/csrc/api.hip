@@ -228,14 +228,15 @@ extern "C" int mdisp_last_kernel_ms(mdisp_ctx* c, int which, float* ms)
     return MDISP_OK;
 }
 
-// Streaming copy used to measure what HBM delivers on this device (the denominator next to the nominal peak):
-// 16 bytes per lane and iteration, grid-stride, nontemporal in both directions.
+// Streaming copy used to measure what HBM delivers on this device (the denominator next to the nominal peak): one
+// 16-byte nontemporal load and store per lane and no loop, i.e. as many short-lived workgroups as the buffer has
+// 4 KiB pieces.  Of the shapes scripts/copy_ubench.hip compares this one is the fastest (6.5 TB/s read + written on
+// 2 GiB; grid-stride loops of 2048 .. 65536 workgroups reach 4.4 .. 5.9 TB/s, hipMemcpyAsync 4.9 TB/s).
 typedef u32 md_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void md_stream_copy_kernel(const md_u32x4* __restrict__ src, md_u32x4* __restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" int mdisp_copy_bandwidth_dev(mdisp_ctx* c, void* d_dst, const void* d_src, size_t bytes, int reps, float* gb_per_s)
@@ -247,7 +248,8 @@ extern "C" int mdisp_copy_bandwidth_dev(mdisp_ctx* c, void* d_dst, const void* d
     MD_HIP(hipEventCreate(&e0));
     MD_HIP(hipEventCreate(&e1));
     const size_t n = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    MD_REQUIRE(n / 256 < 0x7FFFFFFFull, MDISP_E_BADARG, "buffer too large for one launch");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
     md_stream_copy_kernel<<<blocks, 256, 0, c->stream>>>((const md_u32x4*)d_src, (md_u32x4*)d_dst, n);   // warm-up
     MD_HIP(hipEventRecord(e0, c->stream));
     for (int r = 0; r < reps; r++) md_stream_copy_kernel<<<blocks, 256, 0, c->stream>>>((const md_u32x4*)d_src, (md_u32x4*)d_dst, n);

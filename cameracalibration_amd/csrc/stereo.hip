@@ -8,6 +8,7 @@
 // :350-363, :984-1000); in methods/patchmatch.cpp:817-828 the LR check; in methods/methods.cpp:1738,1745
 // cv::remap(INTER_LINEAR).
 #include "common.h"
+#include <algorithm>
 
 #define BT_X 64
 #define BT_Y 16
@@ -137,6 +138,160 @@ __global__ __launch_bounds__(256) void cost_box_wta_kernel(BoxArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Marching variant of the same computation (census / absolute-difference cost -> w x w box with REFLECT_101 -> first
+// minimum), without a workgroup barrier per disparity slice:
+//   * a wave owns 64 consecutive columns (64 - 2h of them are outputs, h columns of halo on either side) and DCH
+//     consecutive disparity slices, and marches down a band of rows;
+//   * per slice a lane keeps the VERTICAL window sum of its column's costs in a register and updates it per row with the
+//     cost of the row that enters the window minus the cost of the row that leaves it (both re-evaluated from the
+//     census / intensity bytes: the cost is two or three instructions, cheaper than keeping w rows of it);
+//   * the HORIZONTAL window sum is the difference of two entries of the wave-wide inclusive prefix sum of those
+//     registers (DPP scan + two lane gathers), so any window up to the halo works with the same code;
+//   * the winner over the wave's slices is kept as a key (sum << 9 | slice), the waves of a workgroup cover the
+//     disparity range and meet once per row in LDS.
+// Hamming costs run as packed u16 pairs (two slices per register); intensity costs as 32-bit values compared as floats,
+// like the slices the reference reads (methods_disp.cpp:357,399).
+__device__ __forceinline__ u32 wave_scan_incl(u32 v)
+{
+    // Hillis-Steele inside each row of 16 lanes, then the row totals across rows (lanes without a source add 0)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);   // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+struct MarchArgs {
+    const u8* ref; size_t rp;
+    const u8* pad; size_t pp;
+    int H, W, D, minD, off0, offStep, win, band, outKind;
+    void* out; size_t op;
+};
+
+template <int KIND, int DCH>
+__global__ __launch_bounds__(512) void cost_box_march_kernel(MarchArgs a)
+{
+    constexpr bool PACKED = KIND == MD_COST_HAMMING || KIND == MD_COST_HAMMING_SQR;
+    constexpr int NV = PACKED ? DCH / 2 : DCH, NQ = DCH / 4;
+    __shared__ unsigned long long keys[2][8][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    const int h = a.win / 2, ow = 64 - 2 * h;
+    const int x0 = blockIdx.x * ow, xl = x0 - h + lane;
+    const int xs = min(max(reflect101_idx(xl, a.W), 0), a.W - 1);          // the column whose costs this lane sums
+    const int yb = blockIdx.y * a.band, ye = min(yb + a.band, a.H);
+    const int k0 = min(wv * DCH, a.D - DCH);                                // the last chunk overlaps its predecessor
+    // slice k compares ref(x) with pad(x + off0 + k*offStep): the chunk's DCH bytes are contiguous; byte j <-> slice kOf(j)
+    const int base = a.offStep > 0 ? xs + a.off0 + k0 : xs + a.off0 - (k0 + DCH - 1);
+    auto k_of = [&](int j) { return a.offStep > 0 ? k0 + j : k0 + DCH - 1 - j; };
+    struct Row { u32 r; u32 p[NQ]; };
+    auto fetch = [&](int y, Row& row) {                                     // y already reflected into the image
+        row.r = a.ref[(size_t)y * a.rp + xs];
+        __builtin_memcpy(row.p, a.pad + (size_t)y * a.pp + base, DCH);
+    };
+    u32 V[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) V[i] = 0;
+    // V += sign * cost(row)
+    auto accumulate = [&](const Row& row, bool add) {
+        if (PACKED) {
+            const u32 m = row.r * 0x01010101u;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const u32 w = row.p[q] ^ m;
+                u32 c0 = (u32)__popc(w & 0x000000FFu) | ((u32)__popc(w & 0x0000FF00u) << 16);
+                u32 c1 = (u32)__popc(w & 0x00FF0000u) | ((u32)__popc(w & 0xFF000000u) << 16);
+                if (KIND == MD_COST_HAMMING_SQR) {
+                    c0 = (c0 & 0xFFFFu) * (c0 & 0xFFFFu) | (((c0 >> 16) * (c0 >> 16)) << 16);
+                    c1 = (c1 & 0xFFFFu) * (c1 & 0xFFFFu) | (((c1 >> 16) * (c1 >> 16)) << 16);
+                }
+                V[2 * q] = add ? V[2 * q] + c0 : V[2 * q] - c0;
+                V[2 * q + 1] = add ? V[2 * q + 1] + c1 : V[2 * q + 1] - c1;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DCH; j++) {
+                const u32 pb = (row.p[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                u32 d = row.r > pb ? row.r - pb : pb - row.r;
+                if (KIND == MD_COST_ABSDIFF_SQR) d *= d;
+                V[j] = add ? V[j] + d : V[j] - d;
+            }
+        }
+    };
+    Row rin, rout;
+    for (int j = -h; j <= h; j++) {                                         // the window of the band's first row
+        fetch(reflect101_idx(yb + j, a.H), rin);
+        accumulate(rin, true);
+    }
+    const int lo = lane - h - 1, hi = min(lane + h, 63);
+    const bool outLane = lane >= h && lane < 64 - h && x0 + lane - h < a.W;
+    for (int y = yb; y < ye; y++) {
+        // requests for the next row's update go out before this row's sums are formed
+        if (y + 1 < ye) {
+            fetch(reflect101_idx(y + h + 1, a.H), rin);
+            fetch(reflect101_idx(y - h, a.H), rout);
+        }
+        unsigned long long best = ~0ull;
+        u32 best32 = 0xFFFFFFFFu;                                           // packed sums stay below 65536: 25-bit keys
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const u32 P = wave_scan_incl(V[i]);
+            const u32 pa = (u32)__shfl((int)P, hi), pb = (u32)__shfl((int)P, max(lo, 0));
+            const u32 hs = pa - (lo >= 0 ? pb : 0u);
+            if (PACKED) {
+                const u32 ka = ((hs & 0xFFFFu) << 9) | (u32)k_of(2 * i), kb = ((hs >> 16) << 9) | (u32)k_of(2 * i + 1);
+                best32 = min(best32, min(ka, kb));
+            } else {
+                // the reference compares the sums as floats: order by the float's bit pattern (non-negative), then by slice
+                const unsigned long long kk = ((unsigned long long)__float_as_uint((float)hs) << 9) | (u32)k_of(i);
+                best = min(best, kk);
+            }
+        }
+        if (PACKED) best = best32;
+        const int par = (y - yb) & 1;
+        keys[par][wv][lane] = best;
+        __syncthreads();
+        if (wv == (y - yb) % nw && outLane) {
+            unsigned long long b = keys[par][0][lane];
+            for (int w2 = 1; w2 < nw; w2++) b = min(b, keys[par][w2][lane]);
+            const int d = (int)(b & 511u) + a.minD;
+            const int gx = x0 + lane - h;
+            if (a.outKind == MD_OUT_U8) reinterpret_cast<u8*>(a.out)[(size_t)y * a.op + gx] = (u8)(d & 0xFF);
+            else if (a.outKind == MD_OUT_F64) reinterpret_cast<double*>(a.out)[(size_t)y * a.op + gx] = (double)d;
+            else reinterpret_cast<float*>(a.out)[(size_t)y * a.op + gx] = (float)d;
+        }
+        if (y + 1 < ye) {
+            accumulate(rin, true);
+            accumulate(rout, false);
+        }
+    }
+}
+
+template <int KIND>
+static int launch_march(hipStream_t s, const MarchArgs& a)
+{
+    const int h = a.win / 2, ow = 64 - 2 * h;
+    const int dch = a.D <= 64 ? 16 : a.D <= 128 ? 32 : 64;
+    const int nw = (a.D + dch - 1) / dch;
+    dim3 grid((a.W + ow - 1) / ow, (a.H + a.band - 1) / a.band);
+    if (dch == 16) cost_box_march_kernel<KIND, 16><<<grid, nw * 64, 0, s>>>(a);
+    else if (dch == 32) cost_box_march_kernel<KIND, 32><<<grid, nw * 64, 0, s>>>(a);
+    else cost_box_march_kernel<KIND, 64><<<grid, nw * 64, 0, s>>>(a);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// can the marching kernel take this problem?  (window within the halo, sums within the packed / keyed ranges, at least
+// one full chunk of slices, at most eight waves)
+static bool march_supported(int D, int win, int costKind)
+{
+    if (D < 16 || D > 512 || win > 33) return false;
+    if (costKind == MD_COST_HAMMING_SQR && win > 15) return false;        // prefix sums of 64 columns stay below 65536
+    return true;
+}
+
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                     int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op)
 {
@@ -144,6 +299,17 @@ int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size
     a.ref = ref; a.rp = rp; a.pad = pad; a.pp = pp; a.H = H; a.W = W; a.Wp = W + maxD;
     a.D = maxD - minD + 1; a.minD = minD; a.off0 = off0; a.offStep = offStep;
     a.win = win; a.costKind = costKind; a.outKind = outKind; a.out = out; a.op = op;
+    if (march_supported(a.D, win, costKind)) {
+        MarchArgs m;
+        m.ref = ref; m.rp = rp; m.pad = pad; m.pp = pp; m.H = H; m.W = W; m.D = a.D; m.minD = minD; m.off0 = off0; m.offStep = offStep;
+        m.win = win; m.outKind = outKind; m.out = out; m.op = op;
+        // a band re-creates its first window from w rows: bands of at least eight windows, and enough of them to fill the GPU
+        m.band = std::max(64, 8 * win);
+        if (costKind == MD_COST_HAMMING) return launch_march<MD_COST_HAMMING>(s, m);
+        if (costKind == MD_COST_HAMMING_SQR) return launch_march<MD_COST_HAMMING_SQR>(s, m);
+        if (costKind == MD_COST_ABSDIFF_SQR) return launch_march<MD_COST_ABSDIFF_SQR>(s, m);
+        return launch_march<MD_COST_ABSDIFF>(s, m);
+    }
     const int h = win / 2;
     a.RX = BT_X + 2 * h; a.RY = BT_Y + 2 * h;
     const int offLast = off0 + offStep * (a.D - 1);

@@ -87,6 +87,28 @@ def test_census_stereo_variants(api, orc, method):
         assert np.array_equal(got, exp)
 
 
+# the marching box kernel: chunk overlap (D not a multiple of the chunk), several waves per workgroup (D up to 300), the
+# smallest D it takes (16) and the tile kernel below it, windows 1 / 33 (its largest) / 35 (tile kernel again), strips and
+# bands that end inside the image, an image narrower than a strip
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape,win,minD,maxD,agg", [((70, 200), 7, 0, 16, 1), ((70, 200), 7, 3, 18, 2), ((33, 130), 3, 0, 99, 1),
+                                                      ((40, 400), 5, 1, 300, 1), ((150, 90), 33, 0, 40, 1), ((150, 90), 35, 0, 40, 1),
+                                                      ((300, 50), 9, 0, 70, 0), ((90, 37), 15, 2, 33, 2), ((64, 64), 17, 0, 20, 2)])
+def test_census_stereo_marching_box_edges(api, orc, left, shape, win, minD, maxD, agg):
+    L, R = rand_pair(41, shape[0], shape[1], min(maxD + 1, shape[1]))
+    got = api.censusStereo(_param(api, L, R, win, minD, maxD, left), api.BASIC_CENSUS, agg)
+    assert np.array_equal(got, orc.census_stereo(L, R, win, minD, maxD, left, orc.BASIC_CENSUS, agg))
+
+
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape,win,minD,maxD", [((70, 200), 7, 0, 16), ((40, 300), 33, 0, 150), ((200, 120), 21, 5, 75), ((60, 90), 35, 0, 30)])
+def test_sad_box_marching_edges(api, orc, left, shape, win, minD, maxD):
+    # squared absolute differences: 32-bit sums, compared as floats
+    L, R = rand_pair(42, shape[0], shape[1], min(maxD + 1, shape[1]))
+    got = api.computeSAD_BFOpti(_param(api, L, R, win, minD, maxD, left))
+    assert np.array_equal(got, orc.sad_box(L, R, win, minD, maxD, left))
+
+
 def test_census_stereo_config2_bit_exact(api, orc):
     # 640x480, D = 64, BASIC_CENSUS, winSize 7 on the synthetic pair
     L, R, _ = api.synth_pair(0x5EED0001, 480, 640, 64)
