@@ -14,7 +14,7 @@ def main():
     path, out = sys.argv[1], sys.argv[2]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(sgm2_\w+<[^>]*>|sgm2_\w+|census3x3_kernel|pad_reflect_lr_kernel)", r["Kernel_Name"])
+        m = re.search(r"(sgm[23]_\w+<[^>]*>|sgm[23]_\w+|census3x3_kernel|pad_reflect_lr_kernel)", r["Kernel_Name"])
         if m:
             agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
     rows = []

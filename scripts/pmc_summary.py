@@ -26,9 +26,9 @@ def main():
     fetch_csv, write_csv, pairs, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, fn = per_kernel(fetch_csv)
     w, _ = per_kernel(write_csv)
-    calls_per_batch = {k: (1 if "sgm2" in k else None) for k in f}
+    calls_per_batch = {k: (1 if ("sgm2" in k or "sgm3" in k) else None) for k in f}
     rows, tot_f, tot_w = [], 0.0, 0.0
-    batches = max(n for k, n in fn.items() if "sgm2" in k)
+    batches = max(n for k, n in fn.items() if ("sgm2" in k or "sgm3" in k))
     for k in sorted(f, key=lambda k: -(f[k] * fn[k])):
         launches_per_batch = fn[k] / batches
         fb = f[k] * 1024 * 2 * launches_per_batch / pairs

@@ -23,13 +23,13 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.Counter()
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(sgm2_\w+<[^>]*>|sgm2_\w+|census3x3_kernel|pad_reflect_lr_kernel)", r["Kernel_Name"])
+        m = re.search(r"(sgm[23]_\w+<[^>]*>|sgm[23]_\w+|census3x3_kernel|pad_reflect_lr_kernel)", r["Kernel_Name"])
         if not m:
             continue
         agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVES":
             launches[m.group(1)] += 1
-    batches = max(v for k, v in launches.items() if "shear" in k or "sweep" in k or "stagger" in k)
+    batches = max(v for k, v in launches.items() if "shear" in k or "sweep" in k or "stagger" in k or "rows" in k)
     rows, total = [], 0.0
     for k, c in agg.items():
         valu = c["SQ_INSTS_VALU"] / batches / pairs
