@@ -54,7 +54,7 @@ EXPORTS = [
     "mdisp_census_transform", "mdisp_hamming_dist", "mdisp_census_stereo", "mdisp_sad_inte", "mdisp_sad_box",
     "mdisp_guided_filter", "mdisp_steer_filter", "mdisp_asw_gifs", "mdisp_sgbm", "mdisp_sgbm_volume", "mdisp_lr_check",
     "mdisp_build_rectify_maps", "mdisp_stereo_rectify", "mdisp_remap", "mdisp_reproject_q", "mdisp_reproject_triangulate", "mdisp_sgbm_workspace_bytes", "mdisp_sgbm_dev",
-    "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev",
+    "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev", "mdisp_sgbm_rows_geometry", "mdisp_sgbm_rows_sweep_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
     "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
@@ -131,6 +131,8 @@ def load():
     lib.mdisp_sgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, sgp]
     lib.mdisp_sgbm_batch_workspace_bytes.restype = C.c_size_t
     lib.mdisp_sgbm_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
+    lib.mdisp_sgbm_rows_geometry.argtypes = [C.c_int, C.c_int, sgp, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.mdisp_sgbm_rows_sweep_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_size_t]
     lib.mdisp_census_stereo_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
     lib.mdisp_census_stereo_dev_noalloc.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, vp]
     lib.mdisp_asw_gifs_band_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_double, C.c_int, C.c_int, C.c_double,

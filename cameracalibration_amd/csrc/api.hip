@@ -742,6 +742,31 @@ extern "C" int mdisp_sgbm_batch_dev(mdisp_ctx* c, const uint8_t* d_left, const u
     return MDISP_OK;
 }
 
+extern "C" int mdisp_sgbm_rows_geometry(int rows, int cols, const mdisp_sgbm_params* p, int* band_rows, size_t* boundary_bytes, size_t* workspace_bytes)
+{
+    md_sgm_plan pl;
+    MD_TRY(md_sgm_plan_make(rows, cols, p, 1, &pl, false, true));
+    if (band_rows) *band_rows = md_sgm2_band_rows(pl);
+    if (boundary_bytes) *boundary_bytes = md_sgm2_boundary_bytes(pl);
+    if (workspace_bytes) *workspace_bytes = pl.total;
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_sgbm_rows_sweep_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                                         const mdisp_sgbm_params* p, int row_begin, int row_end, int direction, int second,
+                                         const void* d_boundary_in, void* d_boundary_out, int16_t* d_disp, void* d_workspace, size_t workspace_bytes)
+{
+    MD_REQUIRE(c && d_left && d_right && p && d_workspace, MDISP_E_BADARG, "null argument (the workspace carries state from the first sweep to the second: the caller must hold it)");
+    MD_REQUIRE(pitch >= (size_t)cols, MDISP_E_BADARG, "pitch smaller than a row");
+    MD_REQUIRE((direction == 0 || direction == 1) && (second == 0 || second == 1), MDISP_E_BADARG, "direction and second are 0 or 1");
+    md_sgm_plan pl;
+    MD_TRY(md_sgm_plan_make(rows, cols, p, 1, &pl, false, true));
+    MD_REQUIRE(workspace_bytes >= pl.total, MDISP_E_BADARG, "workspace too small: %zu < %zu", workspace_bytes, pl.total);
+    MD_HIP(hipSetDevice(c->device));
+    return md_sgm_rows_sweep(c, pl, d_left, d_right, pitch, d_workspace, row_begin, row_end, direction == 1, second == 1,
+                             (const u8*)d_boundary_in, (u8*)d_boundary_out, d_disp);
+}
+
 extern "C" int mdisp_sgbm_dev(mdisp_ctx* c, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                               const mdisp_sgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes)
 {

@@ -92,6 +92,7 @@ struct md_sgm_plan {
     size_t strideS;   // u16 elements between the S volumes of consecutive pairs
     bool use_v2;      // strip-fused two-sweep aggregation (sgm2.hip) instead of per-direction scans
     int sstride;      // u16 elements per pixel in the S volume
+    bool rowBands;    // the row-band schedule whatever the batch size (row-sharded calls)
 };
 // second stream + fork/join events of a context (created on first use); null members = run everything on one stream
 struct md_aux_streams { hipStream_t aux; hipEvent_t ev[3]; };
@@ -106,7 +107,14 @@ size_t md_sgm2_partial_sum_bytes(const md_sgm_plan& pl);   // bytes per slot of 
 int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
                       u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
                       const md_aux_streams* aux = nullptr);
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume = false);
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume = false, bool rowBands = false);
+// one sweep of the row-band schedule over the image rows [r0, r1) of one pair (sgm2.hip / sgm.hip)
+int md_sgm2_band_rows(const md_sgm_plan& pl);            // rows per band: r0 must be a multiple, r1 a multiple or H
+size_t md_sgm2_boundary_bytes(const md_sgm_plan& pl);    // bytes of the path states that cross a band edge
+int md_sgm2_rows_sweep(hipStream_t s, const md_sgm_plan& pl, const u8* cL, const u8* cR, u16* S, u8* extra, int r0, int r1, bool up, bool second,
+                       const u8* bndIn, u8* bndOut, int16_t* dDisp, int* errWord, bool* usedErrWord);
+int md_sgm_rows_sweep(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws, int r0, int r1, bool up, bool second,
+                      const u8* bndIn, u8* bndOut, int16_t* dDisp);
 int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& plan, const u8* dL, const u8* dR, size_t pitch, size_t pairStride,
                int16_t* dDisp, void* ws);
 // aggregation only; *S receives the device volume (pixel stride plan.sstride)

@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(WtaArgs a)
 
 static const int DIRS[8][2] = {{+1, 0}, {-1, 0}, {0, +1}, {0, -1}, {+1, +1}, {-1, +1}, {+1, -1}, {-1, -1}};
 
-int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume)
+int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume, bool rowBands)
 {
+    plan->rowBands = false;
     MD_REQUIRE(batch >= 1 && batch <= 4096, MDISP_E_BADARG, "batch must be in 1..4096");
     plan->batch = batch;
     MD_REQUIRE(p && plan, MDISP_E_BADARG, "null SGM parameters");
@@ -277,6 +278,11 @@ int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm
     plan->off_scratch = off; off += plan->pitchR * H;
     off = md_align(off, 256);
     plan->use_v2 = md_sgm2_supported(*plan) && md_tune(MDISP_TUNE_SGM_PER_DIRECTION) <= 0;
+    if (rowBands) {
+        MD_REQUIRE(md_sgm2_supported(*plan) && plan->npaths == 8 && md_sgm2_u8(*plan) && batch == 1, MDISP_E_UNSUPPORTED,
+                   "the row-band schedule needs eight paths, path states that fit a byte (8 + P2 <= 255) and one pair");
+        plan->use_v2 = true; plan->rowBands = true;
+    }
     plan->sstride = plan->use_v2 ? md_sgm2_slots(*plan) : plan->D;
     // the volume between the two sweeps: one byte per slot where the schedule's four-path sums fit a byte (and the
     // caller does not want the full 16-bit sums exported), else 16 bits
@@ -307,16 +313,12 @@ static int launch_paths(hipStream_t s, const md_sgm_plan& pl, const SgmArgs& a)
     return MDISP_OK;
 }
 
-// dL/dR: first pair; pair i lives at +i*pairStride bytes
-// dDisp == nullptr: leave S8 in the S volume (natural order); otherwise the strip-fused path also
-// runs its fused winner-take-all and writes the final disparity maps.
-static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws,
-                         int16_t* dDisp)
+// census planes of every pair of the batch: the left view as it is, the right view padded by maxD reflected columns
+static int sgm_census_planes(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws)
 {
     hipStream_t s = ctx->stream;
     u8* base = (u8*)ws;
     u8* pad = base + pl.off_pad; u8* scr = base + pl.off_scratch;
-    u16* S = (u16*)(base + pl.off_S);
     const size_t strideL = pl.pitchL * pl.H, strideR = pl.pitchR * pl.H;
     int rc;
     for (int i = 0; i < pl.batch; i++) {
@@ -332,6 +334,21 @@ static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, co
         if ((rc = md_pad_reflect_lr(s, pR, pitch, pl.H, pl.W, pl.maxD, 0, pad, pl.pitchR))) return rc;
         if ((rc = md_census(s, pad, pl.pitchR, pl.H, pl.Wp, pl.census, pl.costWin, cR, pl.pitchR, nullptr))) return rc;
     }
+    return MDISP_OK;
+}
+
+// dL/dR: first pair; pair i lives at +i*pairStride bytes
+// dDisp == nullptr: leave S8 in the S volume (natural order); otherwise the strip-fused path also
+// runs its fused winner-take-all and writes the final disparity maps.
+static int sgm_aggregate(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws,
+                         int16_t* dDisp)
+{
+    hipStream_t s = ctx->stream;
+    u8* base = (u8*)ws;
+    u16* S = (u16*)(base + pl.off_S);
+    const size_t strideL = pl.pitchL * pl.H, strideR = pl.pitchR * pl.H;
+    int rc;
+    if ((rc = sgm_census_planes(ctx, pl, dL, dR, pitch, pairStride, ws))) return rc;
     if (ctx->timing) MD_HIP(hipEventRecord(ctx->ev[2], s));
     if (pl.use_v2) {
         md_aux_streams aux;
@@ -385,4 +402,16 @@ int md_sgm_run(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR
     MD_HIP(hipGetLastError());
     if (ctx->timing) { MD_HIP(hipEventRecord(ctx->ev[5], s)); ctx->ev_valid[2] = true; }
     return MDISP_OK;
+}
+
+// One sweep over the rows [r0, r1) of one pair (see md_sgm2_rows_sweep); the first sweep also prepares the census planes
+// (of the whole views: a few microseconds, and every row range needs its neighbours' rows anyway).
+int md_sgm_rows_sweep(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, void* ws, int r0, int r1, bool up, bool second,
+                      const u8* bndIn, u8* bndOut, int16_t* dDisp)
+{
+    u8* base = (u8*)ws;
+    int rc;
+    if (!second && (rc = sgm_census_planes(ctx, pl, dL, dR, pitch, 0, ws))) return rc;
+    return md_sgm2_rows_sweep(ctx->stream, pl, base + pl.off_cL, base + pl.off_cR, (u16*)(base + pl.off_S), base + pl.off_bnd, r0, r1, up, second,
+                              bndIn, bndOut, dDisp, ctx->sgm_err, &ctx->sgm_pending);
 }

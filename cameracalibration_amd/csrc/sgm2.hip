@@ -818,6 +818,7 @@ struct LrArgs {
     const uint2* rec; size_t strideRec;
     int H, W, D, minD, maxDiff, subpixel;
     int16_t* disp; size_t strideDisp;
+    int y0;         // first image row of the launch
 };
 
 // One workgroup per image row: sub-pixel parabola, disp2 slot election (minimum S, ties to the
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void sgm2_lr_kernel(LrArgs a)
     extern __shared__ u32 lds[];
     u32* key = lds;                                          // [W] (S'min << 16) | (0xFFFF - x)
     int16_t* d1 = reinterpret_cast<int16_t*>(lds + a.W);     // [W]
-    const int y = blockIdx.x, W = a.W, D = a.D;
+    const int y = a.y0 + blockIdx.x, W = a.W, D = a.D;
     const int INVALID = (a.minD - 1) * 16;
     const uint2* rrow = a.rec + (size_t)blockIdx.y * a.strideRec + (size_t)y * W;
     int16_t* drow = a.disp + (size_t)blockIdx.y * a.strideDisp + (size_t)y * W;
@@ -897,7 +898,7 @@ static int sgm2_mode(const md_sgm_plan& pl)
 {
     if (!fits_u8(pl)) return SGM2_PREPASS;
     if (md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) > 0) return SGM2_PREPASS;
-    if (pl.D > 256) return SGM2_ROWS;                 // 512 slots per pixel exist only as row bands
+    if (pl.D > 256 || pl.rowBands) return SGM2_ROWS;  // 512 slots per pixel exist only as row bands
     if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
     if (pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1) return SGM2_ROWS;
     return SGM2_SHEAR;
@@ -915,6 +916,7 @@ static int lanes_per_pixel(const md_sgm_plan& pl)
 {
     const int mode = sgm2_mode(pl);
     if (rows_wide_lanes(pl)) return pl.D > 256 ? 16 : 8;
+    if (pl.rowBands) return 16;                       // row-sharded calls: one geometry per register count
     if ((mode != SGM2_SHEAR && mode != SGM2_ROWS) || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
@@ -935,6 +937,10 @@ size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt);
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b);
+int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
+                  bool s4b, bool up, int role, int band0, int nbands);
+size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl);
+void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke);
 
 static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
 static size_t shear_sync_bytes(int H, int W, int batch, int lpc, int nt)
@@ -1013,18 +1019,14 @@ int launch_shear(hipStream_t s, const md_sgm_plan& pl, const ShearArgs& sa, int 
 // S must hold H*W*md_sgm2_slots() u16 per pair; extra md_sgm2_extra_bytes() bytes
 // naturalOut = 1: S8 is written to S in natural disparity order (volume export / separate WTA).
 // naturalOut = 0: winner-take-all is fused into the up sweep and dDisp receives the final maps.
-int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
-                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
-                      const md_aux_streams* aux)
+static void sgm2_fill_args(const md_sgm_plan& pl, const Sgm2Layout& l, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
+                           u16* S, size_t strideS, u8* extra, int batch, int naturalOut, Sgm2Args& a)
 {
-    Sgm2Args a;
-    const Sgm2Layout l = sgm2_layout(pl, batch);
     a.cL = cL; a.pL = pl.pitchL; a.strideL = strideL;
     a.cR = cR; a.pR = pl.pitchR; a.strideR = strideR;
     a.S = S; a.strideS = strideS;
     a.H = pl.H; a.W = pl.W; a.D = pl.D; a.minD = pl.minD; a.maxD = pl.maxD;
     a.nstrips = l.nstrips;
-    const bool u8m = l.u8m;
     for (int i = 0; i < 4; i++) a.bnd[i] = (u16*)(extra + (size_t)i * l.oneB * batch);
     a.strideB = l.oneB / sizeof(u16);
     u8* hbase = extra + l.bndBytes * batch;
@@ -1041,6 +1043,72 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     a.bias = pl.npaths * pl.P2; a.uniq = pl.uniq;
     a.smallS = ((long)pl.npaths * (8 * pl.costWin * pl.costWin + pl.P2) + 1) * l.dpl < 0x7C00;
     a.S2 = nullptr; a.splitUp = 0;
+}
+
+int md_sgm2_band_rows(const md_sgm_plan& pl)
+{
+    const Sgm2Layout l = sgm2_layout(pl, 1);
+    return md_sgm3_lanes(l.lpc, l.dpl) / l.lpc;
+}
+size_t md_sgm2_boundary_bytes(const md_sgm_plan& pl)
+{
+    const Sgm2Layout l = sgm2_layout(pl, 1);
+    return md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl);
+}
+
+// One sweep of the row-band schedule over the image rows [r0, r1) of one pair: the building block of a pair whose rows are
+// spread over several devices.  `second` = false: the first sweep over these rows (stores the four-path sums in S);
+// true: adds the other four paths, runs the winner-take-all and the left-right check, and writes rows [r0, r1) of dDisp.
+// Either direction may come first.  bndIn: the states of the last row before the range in sweep order (the row r0 - 1 for a
+// down sweep, r1 for an up sweep), as another call's bndOut delivered them; null when the range starts at the image
+// edge.  bndOut (optional): receives the states of the range's last row in sweep order.
+int md_sgm2_rows_sweep(hipStream_t s, const md_sgm_plan& pl, const u8* cL, const u8* cR, u16* S, u8* extra, int r0, int r1, bool up, bool second,
+                       const u8* bndIn, u8* bndOut, int16_t* dDisp, int* errWord, bool* usedErrWord)
+{
+    const Sgm2Layout l = sgm2_layout(pl, 1);
+    MD_REQUIRE(l.mode == SGM2_ROWS && pl.batch == 1, MDISP_E_UNSUPPORTED, "row-sharded SGM needs the row-band schedule (eight paths, byte path states) and one pair per call");
+    const int nt = md_sgm3_lanes(l.lpc, l.dpl), rows = nt / l.lpc, nb = md_sgm3_bands(pl.H, l.lpc, nt);
+    MD_REQUIRE(r0 >= 0 && r0 < r1 && r1 <= pl.H && r0 % rows == 0 && (r1 % rows == 0 || r1 == pl.H), MDISP_E_BADARG,
+               "row range [%d, %d) must start at a multiple of %d rows and end at one or at the last row", r0, r1, rows);
+    MD_REQUIRE(!second || dDisp, MDISP_E_BADARG, "the second sweep writes the disparity rows");
+    Sgm2Args a;
+    sgm2_fill_args(pl, l, cL, pl.pitchL * pl.H, cR, pl.pitchR * pl.H, S, pl.strideS, extra, 1, 0, a);
+    int kb, ke;
+    md_sgm3_band_range(pl.H, l.lpc, nt, up, r0, r1, &kb, &ke);
+    MD_REQUIRE(kb == 0 || bndIn, MDISP_E_BADARG, "rows [%d, %d) do not start at the image edge in this direction: boundary states needed", r0, r1);
+    const size_t bnd = md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl);
+    u8* hand = extra;
+    int* sync = (int*)(extra + l.bndBytes + 2 * l.oneH + l.oneRec);
+    int* prog = sync + 16 + (up ? nb : 0);           // this direction's progress words (one pair)
+    MD_HIP(hipMemsetAsync(sync + (up ? 1 : 0), 0, sizeof(int), s));
+    MD_HIP(hipMemsetAsync(prog, 0, (size_t)nb * sizeof(int), s));
+    if (kb > 0) {
+        MD_HIP(hipMemcpyAsync(hand + (size_t)(kb - 1) * bnd, bndIn, bnd, hipMemcpyDeviceToDevice, s));
+        MD_HIP(hipMemsetD32Async((hipDeviceptr_t)(prog + kb - 1), pl.W, 1, s));     // "the row above is complete"
+    }
+    if (usedErrWord) *usedErrWord = true;
+    const bool s4b = 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
+    MD_TRY(md_sgm3_sweep(s, a, hand, l.bndBytes, sync, errWord, 1, l.lpc, l.dpl, nt, s4b, up, second ? 1 : 0, kb, ke - kb));
+    if (bndOut && ke < nb) MD_HIP(hipMemcpyAsync(bndOut, hand + (size_t)(ke - 1) * bnd, bnd, hipMemcpyDeviceToDevice, s));
+    if (second) {
+        LrArgs l2;
+        l2.rec = a.rec; l2.strideRec = a.strideRec; l2.H = pl.H; l2.W = pl.W; l2.D = pl.D; l2.minD = pl.minD;
+        l2.maxDiff = pl.maxDiff; l2.subpixel = pl.subpixel; l2.disp = dDisp; l2.strideDisp = (size_t)pl.H * pl.W; l2.y0 = r0;
+        sgm2_lr_kernel<<<dim3(r1 - r0, 1), 256, (size_t)pl.W * 6 + 16, s>>>(l2);
+        MD_HIP(hipGetLastError());
+    }
+    return MDISP_OK;
+}
+
+int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t strideL, const u8* cR, size_t strideR,
+                      u16* S, size_t strideS, u8* extra, int batch, int naturalOut, int16_t* dDisp, int* errWord, bool* usedErrWord,
+                      const md_aux_streams* aux)
+{
+    Sgm2Args a;
+    const Sgm2Layout l = sgm2_layout(pl, batch);
+    sgm2_fill_args(pl, l, cL, strideL, cR, strideR, S, strideS, extra, batch, naturalOut, a);
+    const bool u8m = l.u8m;
+    u8* hbase = extra + l.bndBytes * batch;
     u8* afterRec = hbase + 2 * l.oneH * batch + l.oneRec * batch;
     if (l.mode == SGM2_SPLIT && !naturalOut && strideS * sizeof(u16) == l.oneS2) {
         // hscan || prepass, then down sweep || up sweep, then the summing winner-take-all
@@ -1134,7 +1202,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
     if (!naturalOut) {
         LrArgs l2;
         l2.rec = a.rec; l2.strideRec = a.strideRec; l2.H = pl.H; l2.W = pl.W; l2.D = pl.D; l2.minD = pl.minD;
-        l2.maxDiff = pl.maxDiff; l2.subpixel = pl.subpixel; l2.disp = dDisp; l2.strideDisp = (size_t)pl.H * pl.W;
+        l2.maxDiff = pl.maxDiff; l2.subpixel = pl.subpixel; l2.disp = dDisp; l2.strideDisp = (size_t)pl.H * pl.W; l2.y0 = 0;
         sgm2_lr_kernel<<<dim3(pl.H, batch), 256, (size_t)pl.W * 6 + 16, s>>>(l2);
         MD_HIP(hipGetLastError());
     }

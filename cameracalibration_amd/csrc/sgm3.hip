@@ -24,6 +24,7 @@
 // workgroup does the exchange (agent-scope write-through stores, drain, then the progress word; agent-scope loads on
 // the consumer side, parked in LDS one step ahead); every wait is bounded and reports through a sticky error word.
 #include "sgm_lanes_n.h"
+#include <algorithm>
 
 namespace {
 
@@ -35,15 +36,20 @@ struct RowArgs {
     int* err;               // sticky error word (owned by the caller)
     int nb, batch;          // bands per image, pairs per launch
     int band0;              // first band this launch runs (its predecessor's states and progress word are already in place)
+    int vofs;               // logical rows of band 0 that lie before the image (so that band edges fall on the same image rows in both directions)
 };
 
 // LPC lanes share a pixel, each with NRT packed registers (2 NRT disparities); NT compute lanes per workgroup.
 // Byte images of a pixel (LDS states, hand-off rows, byte four-path sums) are stored as NRT/8 planes of LPC*16 bytes:
 // plane p holds dwords 4p .. 4p+3 of every lane's packed state, so that one 16-byte access per lane is contiguous
 // across the pixel's lanes.
-template <bool UP, bool TAIL, bool FUSE, bool S4B, int LPC, int NRT, int NT>
+// UP: the sweep's direction (false: top to bottom, left to right; true: mirrored).  ROLE: 0 = the first sweep over the
+// rows (stores the four-path sum), 1 = the second sweep (adds the stored sum, runs the winner-take-all), 2 = the
+// second sweep with the full sum exported in natural disparity order.  Either direction can be the first sweep.
+template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT>
 __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
 {
+    constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1;
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, SW = PL * PW, NW = NRT / 2;
     const Sgm2Args& a = ra.a;
     __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][packed bytes of the pixel]
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
 
     // ---- compute waves ----
     const int lic = threadIdx.x % LPC, j = threadIdx.x / LPC;
-    const int v = band * SLOTS + j;
-    const bool rowOk = v < H;
-    const int vc = min(v, H - 1);                         // idle slots of the last band request (and drop) a valid row
+    const int v = band * SLOTS + j - ra.vofs;             // logical row; the first vofs slots of band 0 lie before the image
+    const bool rowOk = v >= 0 && v < H;
+    const int vc = min(max(v, 0), H - 1);                 // idle slots of the first / last band request (and drop) a valid row
     const int y = UP ? H - 1 - vc : vc;
     const bool top = v == 0;
     const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         xf = UP ? W - 1 - u : u;
         clw = *reinterpret_cast<const u32*>(cLrow + (xf & ~3));
         __builtin_memcpy(rbw, cRrow + xf, 2 * NRT);
-        if (UP) {
+        if (SECOND) {
             if (S4B) {
 #pragma unroll
                 for (int q = 0; q < PL; q++) {
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         const int x = xf;
         u32 C[NRT], L[NRT], Sacc[NRT];
         cost_n<NRT>(census_byte(clw, x), rbw, C);
-        if (UP) {
+        if (SECOND) {
             if (S4B) unpack_n<NRT>(sbw, Sacc);
             else {
 #pragma unroll
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
             }
             step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic);
 #pragma unroll
-            for (int q = 0; q < NRT; q++) Sacc[q] = UP ? pkadd(Sacc[q], L[q]) : L[q];
+            for (int q = 0; q < NRT; q++) Sacc[q] = SECOND ? pkadd(Sacc[q], L[q]) : L[q];
             u32 N[NRT], ow[NW];
             from_bytes(curA, N);
             step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             lds_put(&st[t & 1][j][1][lic * 4], ow);
-            if (!UP) {
+            if (!SECOND) {
                 if (S4B) {
                     pack_n<NRT>(Sacc, ow);
 #pragma unroll
@@ -329,19 +335,24 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     if (t < T) step(t, V0, V1, DA);
 }
 
-template <int LPC, int NRT, int NT>
-int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, int naturalOut, bool s4b, bool tail)
+template <int LPC, int NRT, int NT, bool BOTH>
+int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role, bool s4b, bool tail)
 {
     const dim3 g((unsigned)nbands * ra.batch);
-#define SGM3_LAUNCH(TAILV, S4BV)                                                                              \
+#define SGM3_ROLE(UPV, ROLEV)                                                                                 \
     do {                                                                                                      \
-        sgm3_rows_kernel<false, TAILV, false, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);                  \
-        if (naturalOut) sgm3_rows_kernel<true, TAILV, false, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);   \
-        else sgm3_rows_kernel<true, TAILV, true, S4BV, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);               \
+        if (tail) { if (s4b) sgm3_rows_kernel<UPV, ROLEV, true, true, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);   \
+                    else sgm3_rows_kernel<UPV, ROLEV, true, false, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra); }    \
+        else { if (s4b) sgm3_rows_kernel<UPV, ROLEV, false, true, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);       \
+               else sgm3_rows_kernel<UPV, ROLEV, false, false, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra); }        \
     } while (0)
-    if (tail) { if (s4b) SGM3_LAUNCH(true, true); else SGM3_LAUNCH(true, false); }
-    else { if (s4b) SGM3_LAUNCH(false, true); else SGM3_LAUNCH(false, false); }
-#undef SGM3_LAUNCH
+    if (!up && role == 0) SGM3_ROLE(false, 0);
+    else if (up && role == 1) SGM3_ROLE(true, 1);
+    else if (up && role == 2) SGM3_ROLE(true, 2);
+    else if (BOTH && up && role == 0) { if constexpr (BOTH) SGM3_ROLE(true, 0); }
+    else if (BOTH && !up && role == 1) { if constexpr (BOTH) SGM3_ROLE(false, 1); }
+    else MD_REQUIRE(false, MDISP_E_UNSUPPORTED, "row bands: this sweep order is not built for the geometry");
+#undef SGM3_ROLE
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }
@@ -351,26 +362,50 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, int naturalOut, bo
 // geometry of the row-band kernels: a pixel has lpc lanes x dpl disparity slots; compute lanes per workgroup (512 slots
 // per pixel: eight rows per band, so that the states and the winner-take-all rows of a band fit the 64 KB of static LDS)
 int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : 256; }
+// bands of the image: one more than the rows need, because the mirrored sweep pads its first band so that band edges fall
+// on the same image rows in both directions
 int md_sgm3_bands(int H, int lpc, int nt) { const int rows = nt / lpc; return (H + rows - 1) / rows; }
-size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt) { return md_align((size_t)md_sgm3_bands(H, lpc, nt) * W * 3 * lpc * dpl, 256); }
-size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * md_sgm3_bands(H, lpc, nt)) * sizeof(int), 256); }
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt) { return md_align((size_t)(md_sgm3_bands(H, lpc, nt) + 1) * W * 3 * lpc * dpl, 256); }
+size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * (md_sgm3_bands(H, lpc, nt) + 1)) * sizeof(int), 256); }
+size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl) { return (size_t)W * 3 * lpc * dpl; }
 
-// Both sweeps over all bands of `batch` pairs.  `a` carries the census planes, the S volume (four-path sums: bytes when
-// s4b, else u16 in register order; with naturalOut the up sweep leaves the full sum there as u16 in natural order) and
-// the winner-take-all records; `sync` must be zero.
-int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                   int naturalOut, bool s4b)
+// Logical bands of one sweep that cover the image rows [r0, r1) (r0 a multiple of the band height, r1 a multiple or H)
+void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke)
+{
+    const int rows = nt / lpc, nb = md_sgm3_bands(H, lpc, nt), Hp = nb * rows;
+    if (!up) { *kb = r0 / rows; *ke = (r1 + rows - 1) / rows; }
+    else { *kb = (Hp - std::min(Hp, (r1 + rows - 1) / rows * rows)) / rows; *ke = (Hp - r0) / rows; }
+}
+
+// One sweep over the logical bands [band0, band0 + nbands) of `batch` pairs.  `a` carries the census planes, the S
+// volume (four-path sums: bytes when s4b, else u16 in register order; with role 2 the sweep leaves the full sum there as
+// u16 in natural order) and the winner-take-all records.  The sweep's ticket and progress words in `sync` must be zero,
+// except the progress word of band0 - 1, which must hold W when that band's states were put into `hand` from outside.
+int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
+                  bool s4b, bool up, int role, int band0, int nbands)
 {
     RowArgs ra;
     ra.a = a; ra.hand = hand; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
-    ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = 0;
+    const int rows = nt / lpc;
+    ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = band0;
+    ra.vofs = up ? ra.nb * rows - a.H : 0;
+    if (nbands < 0) nbands = ra.nb - band0;
     const bool tail = a.tail != 0;
     MD_REQUIRE(nt == md_sgm3_lanes(lpc, dpl) && (dpl == 16 || dpl == 32), MDISP_E_BADARG, "row bands: unsupported geometry");
+    MD_REQUIRE(band0 >= 0 && nbands >= 1 && band0 + nbands <= ra.nb, MDISP_E_BADARG, "row bands: band range outside the image");
     if (dpl == 32) {
-        if (lpc == 16) return launch_rows<16, 16, 128>(s, ra, ra.nb, naturalOut, s4b, tail);
+        if (lpc == 16) return launch_rows<16, 16, 128, true>(s, ra, nbands, up, role, s4b, tail);
         MD_REQUIRE(false, MDISP_E_BADARG, "row bands: unsupported geometry");
     }
-    if (lpc == 4) return launch_rows<4, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
-    if (lpc == 8) return launch_rows<8, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
-    return launch_rows<16, 8, 256>(s, ra, ra.nb, naturalOut, s4b, tail);
+    if (lpc == 4) return launch_rows<4, 8, 256, false>(s, ra, nbands, up, role, s4b, tail);
+    if (lpc == 8) return launch_rows<8, 8, 256, false>(s, ra, nbands, up, role, s4b, tail);
+    return launch_rows<16, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
+}
+
+// Both sweeps over all bands of `batch` pairs (down first); `sync` must be zero.
+int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
+                   int naturalOut, bool s4b)
+{
+    MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1));
+    return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1);
 }

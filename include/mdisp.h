@@ -349,6 +349,30 @@ int mdisp_sgbm_batch_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_rig
                          int rows, int cols, size_t pitch, const mdisp_sgbm_params* p, int16_t* d_disp,
                          void* d_workspace, size_t workspace_bytes);
 
+/* ONE pair whose rows are spread over several devices (a single large pair, where the latency of the pair counts and
+ * pair-sharding has nothing to shard).  The semi-global paths cross every row boundary, so the devices run the two
+ * sweeps of the aggregation over their own row range and hand the path states of the boundary row to the neighbour:
+ *   mdisp_sgbm_rows_geometry    band_rows: row ranges start at multiples of it (and end at one, or at the last row);
+ *                               boundary_bytes: size of one boundary-state buffer; workspace_bytes: device workspace a
+ *                               participant needs (it keeps the four-path sums between its two sweeps there, so the
+ *                               same workspace must be passed to both sweeps of a pair)
+ *   mdisp_sgbm_rows_sweep_dev   one sweep over rows [row_begin, row_end) of the pair.  direction 0 runs top to bottom
+ *                               (paths from the left, the top-left, the top and the top-right), 1 bottom to top (the
+ *                               four opposite paths).  second = 0: the first of the participant's two sweeps; second =
+ *                               1: its other sweep, which also writes rows [row_begin, row_end) of d_disp (a full HxW
+ *                               int16 map; the other rows are left alone).  d_boundary_in: the states of the row just
+ *                               before the range in sweep order, as the neighbour's d_boundary_out delivered them (NULL
+ *                               at the image edge); d_boundary_out: receives the states of the range's last row in
+ *                               sweep order (NULL when nobody needs them).
+ * Both views must be present on every participant (the cost of a row reads that row only, the census its two
+ * neighbours).  Any order of sweeps that respects the boundary dependencies gives the map of mdisp_sgbm_dev bit for
+ * bit.  Needs eight paths and 8 + P2 <= 255.  The reference computes a pair on one thread (stereoMatching.cpp:2110
+ * computeDisparity); it has no counterpart of the split. */
+int mdisp_sgbm_rows_geometry(int rows, int cols, const mdisp_sgbm_params* p, int* band_rows, size_t* boundary_bytes, size_t* workspace_bytes);
+int mdisp_sgbm_rows_sweep_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
+                              const mdisp_sgbm_params* p, int row_begin, int row_end, int direction, int second,
+                              const void* d_boundary_in, void* d_boundary_out, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
+
 /* census stereo on device buffers; d_disp: device double HxW */
 int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                             const mdisp_param* p, int census_method, int agg_mode, double* d_disp);
