@@ -18,7 +18,8 @@ void mdisp_set_error(const char* fmt, ...)
 
 extern "C" const char* mdisp_last_error(void) { return g_err; }
 
-static int g_tune[MDISP_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_tune[MDISP_TUNE_COUNT];
+static const bool g_tune_ready = [] { for (int& v : g_tune) v = -1; return true; }();      // -1: the built-in choice
 int md_tune(int key) { return key >= 0 && key < MDISP_TUNE_COUNT ? g_tune[key] : -1; }
 void md_tune_clear(int key) { if (key >= 0 && key < MDISP_TUNE_COUNT) g_tune[key] = -1; }
 extern "C" int mdisp_tuning_set(int key, int value)

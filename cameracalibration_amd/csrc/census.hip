@@ -5,6 +5,7 @@
 // copyMakeBorder(BORDER_REFLECT) calls at :224,268,862,1005 and checkImg's cvtColor (:138-141).
 #include "common.h"
 #include <math.h>
+#include <stdint.h>
 
 // cv::borderInterpolate(BORDER_REFLECT): fedcba|abcdef|fedcba
 __device__ __forceinline__ int reflect_idx(int p, int n)
@@ -80,6 +81,82 @@ __global__ __launch_bounds__(256) void census3x3_kernel(const u8* __restrict__ s
             u32 code = 0;
             if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
                 u32 c = r1[i];
+                code |= (u32)(r0[i - 1] >= c) << 7;
+                code |= (u32)(r0[i] >= c) << 6;
+                code |= (u32)(r0[i + 1] >= c) << 5;
+                code |= (u32)(r1[i + 1] >= c) << 4;
+                code |= (u32)(r2[i + 1] >= c) << 3;
+                code |= (u32)(r2[i] >= c) << 2;
+                code |= (u32)(r2[i - 1] >= c) << 1;
+                code |= (u32)(r1[i - 1] >= c) << 0;
+                if (USE_LUT) code = slut[code];
+            }
+            out |= code << (8 * i);
+        }
+        *reinterpret_cast<u32*>(dst + (size_t)y * dp + xg) = out;
+    }
+}
+
+// The census planes of a batch of stereo pairs in one launch: blockIdx.z = 2 * pair + view.  View 0 is the left image as
+// it is; view 1 is the right image with `left` reflected columns in front of it (what pad_reflect_lr_kernel followed by
+// census3x3_kernel would give), read straight from the unpadded source.
+struct CensusPairs {
+    const u8* srcL; const u8* srcR; size_t sp, pairStride;
+    int H, W, left;
+    u8* dstL; size_t dpL, strideL;
+    u8* dstR; size_t dpR, strideR;
+    int alignedL;           // the left rows can be read as dwords
+};
+template <bool USE_LUT>
+__global__ __launch_bounds__(256) void census3x3_pairs_kernel(CensusPairs a, CensusLut lut)
+{
+    __shared__ u32 tile[(CT_H + 2) * (CT_LW / 4)];
+    __shared__ u8 slut[256];
+    const int view = blockIdx.z & 1, pair = blockIdx.z >> 1;
+    const int H = a.H, W = view ? a.W + a.left : a.W, left = view ? a.left : 0;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    if (x0 >= W) return;
+    const u8* src = (view ? a.srcR : a.srcL) + (size_t)pair * a.pairStride;
+    u8* dst = view ? a.dstR + (size_t)pair * a.strideR : a.dstL + (size_t)pair * a.strideL;
+    const size_t dp = view ? a.dpR : a.dpL;
+    const int t = threadIdx.x;
+    if (USE_LUT) slut[t] = lut.t[t];
+    constexpr int DW = CT_LW / 4;
+    const bool dwords = !view && a.alignedL;
+    for (int i = t; i < (CT_H + 2) * DW; i += 256) {
+        const int r = i / DW, c = i % DW;
+        const int y = y0 - 1 + r, x = x0 - 4 + 4 * c;
+        u32 v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const u8* row = src + (size_t)y * a.sp;
+            if (dwords) v = *reinterpret_cast<const u32*>(row + x);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (x + k < W) v |= (u32)row[reflect_idx(x + k - left, a.W)] << (8 * k);
+            }
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int tx = t & 63, ty = t >> 6;
+    const u8* tb = reinterpret_cast<const u8*>(tile);
+#pragma unroll
+    for (int rr = 0; rr < CT_H / 4; rr++) {
+        const int ly = ty + 4 * rr, y = y0 + ly;
+        if (y >= H) break;
+        const int xg = x0 + 4 * tx;
+        if (xg >= W) continue;
+        const u8* r0 = tb + (ly + 0) * CT_LW + 4 + 4 * tx;
+        const u8* r1 = r0 + CT_LW;
+        const u8* r2 = r1 + CT_LW;
+        u32 out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = xg + i;
+            u32 code = 0;
+            if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+                const u32 c = r1[i];
                 code |= (u32)(r0[i - 1] >= c) << 7;
                 code |= (u32)(r0[i] >= c) << 6;
                 code |= (u32)(r0[i + 1] >= c) << 5;
@@ -337,6 +414,34 @@ int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* g
 {
     dim3 grid((W + 255) / 256, H);
     bgr2gray_kernel<<<grid, 256, 0, s>>>(bgr, spitch, H, W, gray, dpitch);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// Census planes of `batch` stereo pairs (pair i at +i*pairStride bytes of dL / dR, rows `pitch` bytes apart) in one
+// launch: cL receives the census of the left views (W columns), cR that of the right views with `left` reflected
+// columns in front (W + left columns).  3x3 census methods only (basic, rotation-invariant, uniform).  The destination
+// pitches must be multiples of 4 that cover the widths rounded up to 4.
+int md_census_pairs(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, int batch, int H, int W, int left, int method,
+                    u8* cL, size_t pitchL, size_t strideL, u8* cR, size_t pitchR, size_t strideR)
+{
+    MD_REQUIRE(method == MDISP_BASIC_CENSUS || method == MDISP_ROTATION_INVARIANT_CENSUS || method == MDISP_UNIFORM_CENSUS, MDISP_E_UNSUPPORTED,
+               "batched census: 3x3 methods only");
+    MD_REQUIRE(pitchL % 4 == 0 && pitchR % 4 == 0 && pitchL >= md_align((size_t)W, 4) && pitchR >= md_align((size_t)(W + left), 4), MDISP_E_BADARG,
+               "batched census: destination pitch");
+    CensusPairs a;
+    a.srcL = dL; a.srcR = dR; a.sp = pitch; a.pairStride = pairStride; a.H = H; a.W = W; a.left = left;
+    a.dstL = cL; a.dpL = pitchL; a.strideL = strideL; a.dstR = cR; a.dpR = pitchR; a.strideR = strideR;
+    a.alignedL = pitch % 4 == 0 && pitch >= md_align((size_t)W, 4) && pairStride % 4 == 0 && ((uintptr_t)dL & 3) == 0;
+    CensusLut l;
+    memset(l.t, 0, 256);
+    const dim3 grid((W + left + CT_W - 1) / CT_W, (H + CT_H - 1) / CT_H, 2 * batch);
+    MD_REQUIRE(2 * batch <= 65535, MDISP_E_RANGE, "batched census: too many pairs for one launch");
+    if (method == MDISP_BASIC_CENSUS) census3x3_pairs_kernel<false><<<grid, 256, 0, s>>>(a, l);
+    else {
+        if (method == MDISP_ROTATION_INVARIANT_CENSUS) ri_table(l.t); else uniform_table(l.t);
+        census3x3_pairs_kernel<true><<<grid, 256, 0, s>>>(a, l);
+    }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }

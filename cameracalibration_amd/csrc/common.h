@@ -75,6 +75,8 @@ __host__ __device__ static inline int md_align_dev(int v, int a) { return (v + a
 
 // ---- kernels' host launchers (all enqueue on `s`, no sync) ----
 // census.hip
+int md_census_pairs(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, int batch, int H, int W, int left, int method,
+                    u8* cL, size_t pitchL, size_t strideL, u8* cR, size_t pitchR, size_t strideR);
 int md_pad_reflect_lr(hipStream_t s, const u8* src, size_t spitch, int H, int W, int left, int right, u8* dst, size_t dpitch);
 int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int method, int arg, u8* dst, size_t dpitch,
               u8* scratch /* H*dpitch (rounded up to 256) + MD_CENSUS_SCRATCH_TAIL bytes, needed by the MULTISCALE variants */);

@@ -316,25 +316,10 @@ static int launch_paths(hipStream_t s, const md_sgm_plan& pl, const SgmArgs& a)
 // census planes of every pair of the batch: the left view as it is, the right view padded by maxD reflected columns
 static int sgm_census_planes(mdisp_ctx* ctx, const md_sgm_plan& pl, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, void* ws)
 {
-    hipStream_t s = ctx->stream;
     u8* base = (u8*)ws;
-    u8* pad = base + pl.off_pad; u8* scr = base + pl.off_scratch;
-    const size_t strideL = pl.pitchL * pl.H, strideR = pl.pitchR * pl.H;
-    int rc;
-    for (int i = 0; i < pl.batch; i++) {
-        u8* cL = base + pl.off_cL + (size_t)i * strideL; u8* cR = base + pl.off_cR + (size_t)i * strideR;
-        const u8* pL = dL + (size_t)i * pairStride; const u8* pR = dR + (size_t)i * pairStride;
-        // census reads rows as dwords: stage the left image when the caller's pitch is not a multiple of 4
-        const u8* srcL = pL; size_t spL = pitch;
-        if (pitch % 4 != 0 || pitch < md_align(pl.W, 4)) {
-            MD_HIP(hipMemcpy2DAsync(scr, pl.pitchL, pL, pitch, pl.W, pl.H, hipMemcpyDeviceToDevice, s));
-            srcL = scr; spL = pl.pitchL;
-        }
-        if ((rc = md_census(s, srcL, spL, pl.H, pl.W, pl.census, pl.costWin, cL, pl.pitchL, nullptr))) return rc;
-        if ((rc = md_pad_reflect_lr(s, pR, pitch, pl.H, pl.W, pl.maxD, 0, pad, pl.pitchR))) return rc;
-        if ((rc = md_census(s, pad, pl.pitchR, pl.H, pl.Wp, pl.census, pl.costWin, cR, pl.pitchR, nullptr))) return rc;
-    }
-    return MDISP_OK;
+    // one launch for both views of every pair; the right view's reflected columns are read from the unpadded image
+    return md_census_pairs(ctx->stream, dL, dR, pitch, pl.batch > 1 ? pairStride : 0, pl.batch, pl.H, pl.W, pl.maxD, pl.census,
+                           base + pl.off_cL, pl.pitchL, pl.pitchL * pl.H, base + pl.off_cR, pl.pitchR, pl.pitchR * pl.H);
 }
 
 // dL/dR: first pair; pair i lives at +i*pairStride bytes

@@ -36,6 +36,9 @@ struct RowArgs {
     int* err;               // sticky error word (owned by the caller)
     int nb, batch;          // bands per image, pairs per launch
     int band0;              // first band this launch runs (its predecessor's states and progress word are already in place)
+    int nbands;             // bands this launch runs
+    int group;              // pairs dispatched together: tickets run band-major inside a group of pairs, group after group
+    int slack;              // pixels a band stays behind its predecessor beyond the two it needs
     int vofs;               // logical rows of band 0 that lie before the image (so that band edges fall on the same image rows in both directions)
 };
 
@@ -61,8 +64,11 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     if (FUSE) init_excl_mask_n<NRT>(exclMask);
     __syncthreads();
     const int ticket = s_ticket;
-    const int ord = ticket / ra.batch, pair = ticket - ord * ra.batch;
-    const int band = ra.band0 + ord;                      // bands in dependency order
+    // tickets: group after group of pairs; inside a group band after band (dependency order), pair after pair
+    const int perGroup = ra.group * ra.nbands, grp = ticket / perGroup, rem = ticket - grp * perGroup;
+    const int gsz = min(ra.group, ra.batch - grp * ra.group);
+    const int ord = rem / gsz, pair = grp * ra.group + (rem - ord * gsz);
+    const int band = ra.band0 + ord;
     const int H = a.H, W = a.W;
     const int T = W + 2 * (SLOTS - 1);                    // steps: slot j works on u = t - 2j
     u8* hand = ra.hand + (size_t)pair * ra.strideHand;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         auto request = [&](int i, u32 (&w)[NW]) {
             const bool mine = wants(i);
             if (!__any(mine)) return;
-            const int need = i + 2;                       // pixels the band above must have published
+            const int need = min(i + 2 + ra.slack, W);    // pixels the band above must have published (two, plus the slack that decouples the bands)
             if (seen < need) {
                 unsigned long long t0 = 0;
                 for (int it = 0;; it++) {
@@ -390,6 +396,9 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = band0;
     ra.vofs = up ? ra.nb * rows - a.H : 0;
     if (nbands < 0) nbands = ra.nb - band0;
+    ra.nbands = nbands;
+    { const int g = md_tune(MDISP_TUNE_SGM_PAIR_GROUP); ra.group = g > 0 ? std::min(g, batch) : batch; }
+    { const int sl = md_tune(MDISP_TUNE_SGM_BAND_SLACK); ra.slack = sl > 0 ? sl : 0; }
     const bool tail = a.tail != 0;
     MD_REQUIRE(nt == md_sgm3_lanes(lpc, dpl) && (dpl == 16 || dpl == 32), MDISP_E_BADARG, "row bands: unsupported geometry");
     MD_REQUIRE(band0 >= 0 && nbands >= 1 && band0 + nbands <= ra.nb, MDISP_E_BADARG, "row bands: band range outside the image");

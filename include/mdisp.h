@@ -436,7 +436,9 @@ enum {
     MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other  */
     MDISP_TUNE_SGM_PIPELINE = 7,       /* batches: 0 = row bands with four paths per sweep (default), 1 = sheared strips with a separate horizontal scan */
     MDISP_TUNE_SGM_PLANT_ERROR = 8,    /* 1: the next pipelined SGM call finds its hand-off error word already set  */
-    MDISP_TUNE_COUNT = 9
+    MDISP_TUNE_SGM_BAND_SLACK = 9,     /* row bands: pixels a band stays behind its predecessor beyond the minimum  */
+    MDISP_TUNE_SGM_PAIR_GROUP = 10,    /* row bands: pairs whose bands are dispatched together (band-major inside a group) */
+    MDISP_TUNE_COUNT = 11
 };
 int mdisp_tuning_set(int key, int value);
 int mdisp_tuning_get(int key);
