@@ -213,6 +213,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     const int aboveStride = j > 0 ? SLOTS * 3 * SW : 3 * SW;
 
     u32 Nh[NRT];                       // the path that runs along the row
+    u32 ooh = 0;                       // its minimum (only where the state is kept un-normalised: no masked disparities)
     fresh(Nh);
     u32 clw = 0, rbw[NW], sbw[NW], Sn[NRT];
 #pragma unroll
@@ -283,9 +284,10 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
                     if (top) Vuse[q] = 0;
                     if (top || firstCol) D[q] = 0;
                 }
-                if (firstCol) fresh(Nh);
+                if (firstCol) { fresh(Nh); ooh = 0; }
             }
-            step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic);
+            if (TAIL) step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic);
+            else step_lazy_n<LPC, NRT>(Nh, ooh, C, P1P1, P2P2, L, lic);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = SECOND ? pkadd(Sacc[q], L[q]) : L[q];
             u32 N[NRT], ow[NW];

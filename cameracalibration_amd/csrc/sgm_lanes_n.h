@@ -98,6 +98,41 @@ __device__ __forceinline__ void step_n(u32 (&N)[NRT], const u32 (&C)[NRT], u32 P
     for (int r = 0; r < NRT; r++) N[r] = pksub(TAIL ? L[r] | tail[r] : L[r], mm);
 }
 
+// The same step for a path without masked disparities whose state is kept as L' itself, together with oo = min L'
+// (broadcast to both halves): L'(d) = C(d) + min(L(d), oo + P2, P1 + min(L(d-1), L(d+1))) - oo.  Every operand of the
+// minimum is at least oo in both halves, so |m - oo| + C is one v_sad_u32 and nothing is subtracted afterwards.
+template <int LPC, int NRT>
+__device__ __forceinline__ void step_lazy_n(u32 (&N)[NRT], u32& oo, const u32 (&C)[NRT], u32 P1P1, u32 P2P2, u32 (&L)[NRT], int lic)
+{
+    u32 prevL = dpp_keep<DPP_ROW_SHR1>(INF2, N[NRT - 1]);
+    u32 nextF = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
+    if (LPC < 16) {
+        prevL = lic == 0 ? INF2 : prevL;
+        nextF = lic == LPC - 1 ? INF2 : nextF;
+    }
+    u32 O[NRT + 2];
+    O[0] = __builtin_amdgcn_alignbit(N[NRT - 1], prevL, 16);
+    O[NRT + 1] = __builtin_amdgcn_alignbit(nextF, N[0], 16);
+#pragma unroll
+    for (int r = 0; r < NRT; r++) O[r + 1] = N[r];
+    const u32 P2o = pkadd(P2P2, oo);
+    u32 mn = 0, held = 0;
+#pragma unroll
+    for (int r = 0; r < NRT; r++) {
+        const u32 t = pkadd(pkmin(O[r], O[r + 2]), P1P1);
+        const u32 m = pkmin3(O[r + 1], P2o, t);
+        u32 Lr;
+        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(Lr) : "v"(m), "v"(oo), "v"(C[r]));
+        L[r] = Lr;
+        N[r] = Lr;
+        if (r & 1) mn = r == 1 ? pkmin(held, Lr) : pkmin3(mn, held, Lr);
+        else held = Lr;
+    }
+    u32 m1 = min(mn & 0xFFFFu, mn >> 16);
+    m1 = row_min16<LPC>(m1);
+    oo = m1 | (m1 << 16);
+}
+
 // One step of a path whose state is handed on as bytes: consumes the unpacked predecessor state N, returns L' and the
 // packed normalised state.  Without masked disparities the minimum is subtracted from the packed bytes (every byte is
 // at least the minimum, so no borrow crosses a byte): half the subtractions.
