@@ -896,11 +896,13 @@ static int path_waves_max_batch()
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
-    if (!fits_u8(pl)) return SGM2_PREPASS;
+    const bool rowsWanted = pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1;
+    if (!fits_u8(pl))      // 16-bit path states: row bands for batches, upright strips + pre-pass for a few pairs
+        return rowsWanted && pl.batch > split_max_batch() && md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) <= 0 ? SGM2_ROWS : SGM2_PREPASS;
     if (md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) > 0) return SGM2_PREPASS;
     if (pl.D > 256 || pl.rowBands) return SGM2_ROWS;  // 512 slots per pixel exist only as row bands
     if (pl.npaths == 8 && pl.batch <= split_max_batch()) return SGM2_SPLIT;
-    if (pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1) return SGM2_ROWS;
+    if (rowsWanted) return SGM2_ROWS;
     return SGM2_SHEAR;
 }
 
@@ -916,7 +918,7 @@ static int lanes_per_pixel(const md_sgm_plan& pl)
 {
     const int mode = sgm2_mode(pl);
     if (rows_wide_lanes(pl)) return pl.D > 256 ? 16 : 8;
-    if (pl.rowBands) return 16;                       // row-sharded calls: one geometry per register count
+    if (pl.rowBands || (mode == SGM2_ROWS && !fits_u8(pl))) return 16;      // row-sharded calls, 16-bit path states: one geometry
     if ((mode != SGM2_SHEAR && mode != SGM2_ROWS) || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
@@ -933,13 +935,13 @@ static int shear_nt(const md_sgm_plan& pl, int batch)
 // sgm3.hip
 int md_sgm3_lanes(int lpc, int dpl);
 int md_sgm3_bands(int H, int lpc, int nt);
-size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt);
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt, bool s16);
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                   int naturalOut, bool s4b);
+                   int naturalOut, bool s4b, bool s16);
 int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                  bool s4b, bool up, int role, int band0, int nbands);
-size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl);
+                  bool s4b, bool up, int role, int band0, int nbands, bool s16);
+size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl, bool s16);
 void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke);
 
 static size_t shear_hand_bytes(int H, int W, int lpc, int nt) { return md_align((size_t)H * shear_strips(H, W, nt / lpc) * 3 * lpc * DPL, 256); }
@@ -958,7 +960,7 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
     l.cw = CW;
     l.nstrips = (pl.W + l.cw - 1) / l.cw;
     if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // hand-off rows (sized for the narrower strips)
-    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl)); }   // last-row states of every band
+    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), !l.u8m); }   // last-row states of every band
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = l.mode == SGM2_ROWS ? 0 : md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
@@ -1053,7 +1055,7 @@ int md_sgm2_band_rows(const md_sgm_plan& pl)
 size_t md_sgm2_boundary_bytes(const md_sgm_plan& pl)
 {
     const Sgm2Layout l = sgm2_layout(pl, 1);
-    return md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl);
+    return md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl, false);
 }
 
 // One sweep of the row-band schedule over the image rows [r0, r1) of one pair: the building block of a pair whose rows are
@@ -1076,7 +1078,7 @@ int md_sgm2_rows_sweep(hipStream_t s, const md_sgm_plan& pl, const u8* cL, const
     int kb, ke;
     md_sgm3_band_range(pl.H, l.lpc, nt, up, r0, r1, &kb, &ke);
     MD_REQUIRE(kb == 0 || bndIn, MDISP_E_BADARG, "rows [%d, %d) do not start at the image edge in this direction: boundary states needed", r0, r1);
-    const size_t bnd = md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl);
+    const size_t bnd = md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl, false);
     u8* hand = extra;
     int* sync = (int*)(extra + l.bndBytes + 2 * l.oneH + l.oneRec);
     int* prog = sync + 16 + (up ? nb : 0);           // this direction's progress words (one pair)
@@ -1088,7 +1090,7 @@ int md_sgm2_rows_sweep(hipStream_t s, const md_sgm_plan& pl, const u8* cL, const
     }
     if (usedErrWord) *usedErrWord = true;
     const bool s4b = 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-    MD_TRY(md_sgm3_sweep(s, a, hand, l.bndBytes, sync, errWord, 1, l.lpc, l.dpl, nt, s4b, up, second ? 1 : 0, kb, ke - kb));
+    MD_TRY(md_sgm3_sweep(s, a, hand, l.bndBytes, sync, errWord, 1, l.lpc, l.dpl, nt, s4b, up, second ? 1 : 0, kb, ke - kb, false));
     if (bndOut && ke < nb) MD_HIP(hipMemcpyAsync(bndOut, hand + (size_t)(ke - 1) * bnd, bnd, hipMemcpyDeviceToDevice, s));
     if (second) {
         LrArgs l2;
@@ -1158,7 +1160,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
         }
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), naturalOut, s4b));
+        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), naturalOut, s4b, !l.u8m));
     } else if (l.mode == SGM2_SHEAR) {
         ShearArgs sa;
         sa.a = a;

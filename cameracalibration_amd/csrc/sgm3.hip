@@ -49,11 +49,18 @@ struct RowArgs {
 // UP: the sweep's direction (false: top to bottom, left to right; true: mirrored).  ROLE: 0 = the first sweep over the
 // rows (stores the four-path sum), 1 = the second sweep (adds the stored sum, runs the winner-take-all), 2 = the
 // second sweep with the full sum exported in natural disparity order.  Either direction can be the first sweep.
-template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT>
-__global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
+// S16: the three states that leave the registers travel as 16-bit values (path values that do not fit a byte: 8 + P2 >
+// 255) -- twice the LDS and hand-off bytes, no pack / unpack.
+template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false>
+__global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
 {
     constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1;
-    constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, SW = PL * PW, NW = NRT / 2;
+    constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, NW = NRT / 2;
+    constexpr int SWN = S16 ? NRT : NRT / 2;      // dwords of one path state per lane
+    constexpr int PLS = SWN / 4;                  // ... as 16-byte planes
+    constexpr int SW = PLS * PW;                  // dwords of one path state per pixel
+    constexpr int DPB = SW * 4;                   // bytes of one path state per pixel
+    static_assert(!(S16 && S4B), "16-bit path states never have byte sums");
     const Sgm2Args& a = ra.a;
     __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][packed bytes of the pixel]
     __shared__ u32 hin[2][3][SW];           // the band above's states for slot 0, same parity rule
@@ -73,16 +80,16 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     const int T = W + 2 * (SLOTS - 1);                    // steps: slot j works on u = t - 2j
     u8* hand = ra.hand + (size_t)pair * ra.strideHand;
     const bool hasPrev = band > 0, hasNext = band + 1 < ra.nb;
-    auto lds_get = [&](const u32* p, u32 (&w)[NW]) {       // p: the lane's first dword of plane 0
+    auto lds_get = [&](const u32* p, u32 (&w)[SWN]) {      // p: the lane's first dword of plane 0
 #pragma unroll
-        for (int q = 0; q < PL; q++) {
+        for (int q = 0; q < PLS; q++) {
             const uint4 v = *reinterpret_cast<const uint4*>(p + q * PW);
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
     };
-    auto lds_put = [&](u32* p, const u32 (&w)[NW]) {
+    auto lds_put = [&](u32* p, const u32 (&w)[SWN]) {
 #pragma unroll
-        for (int q = 0; q < PL; q++) *reinterpret_cast<uint4*>(p + q * PW) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        for (int q = 0; q < PLS; q++) *reinterpret_cast<uint4*>(p + q * PW) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     };
 
     if (threadIdx.x >= NT) {
@@ -94,10 +101,10 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         int* errWord = ra.err;
         int seen = 0;
         const __amdgpu_buffer_rsrc_t rsrc = hand_rsrc(hand, ra.strideHand);      // the pair's rows: below 4 GB
-        auto hand_slot = [&](int bnd, int u, int wh) -> u32 { return (u32)((((size_t)bnd * W + u) * 3 + wh) * DP + lic * 16); };
+        auto hand_slot = [&](int bnd, int u, int wh) -> u32 { return (u32)((((size_t)bnd * W + u) * 3 + wh) * DPB + lic * 16); };
         // slot 0 consumes in step i (i >= -1) the states of pixel i + 1 of the row above
         auto wants = [&](int i) -> bool { return hasPrev && which < 3 && i + 1 < W; };
-        auto request = [&](int i, u32 (&w)[NW]) {
+        auto request = [&](int i, u32 (&w)[SWN]) {
             const bool mine = wants(i);
             if (!__any(mine)) return;
             const int need = min(i + 2 + ra.slack, W);    // pixels the band above must have published (two, plus the slack that decouples the bands)
@@ -128,13 +135,13 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
             if (mine) {
                 const u32 src = hand_slot(band - 1, i + 1, which);
 #pragma unroll
-                for (int q = 0; q < PL; q++) {
+                for (int q = 0; q < PLS; q++) {
                     const uint4 v = hand_load16(rsrc, src + q * LPC * 16);
                     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
                 }
             }
         };
-        auto park = [&](int i, const u32 (&w)[NW]) {      // hand the fetched states of step i to slot 0
+        auto park = [&](int i, const u32 (&w)[SWN]) {      // hand the fetched states of step i to slot 0
             if (wants(i)) lds_put(&hin[(i + 1) & 1][which][lic * 4], w);
         };
         auto send = [&](int t) {                           // step t has been computed: the last slot's states are in st[t & 1]
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
             if (hasNext && which < 3 && u >= 0 && u < W) {
                 const u32 dst = hand_slot(band, u, which);
 #pragma unroll
-                for (int q = 0; q < PL; q++)
+                for (int q = 0; q < PLS; q++)
                     hand_store16(rsrc, dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][q * PW + lic * 4]));
             }
         };
@@ -153,9 +160,9 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         // Software pipeline, one step per pixel, that never waits for an operation issued in the same step: step t first
         // drains what step t-1 issued (stores of step t-2's states, loads for step t+1, a sample of the neighbour's
         // progress), then announces step t-2, sends step t-1, parks step t+1's states in LDS and requests step t+2's.
-        u32 w[NW];
+        u32 w[SWN];
 #pragma unroll
-        for (int q = 0; q < NW; q++) w[q] = 0;
+        for (int q = 0; q < SWN; q++) w[q] = 0;
         request(-1, w);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         park(-1, w);
@@ -200,8 +207,11 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
 #pragma unroll
         for (int q = 0; q < NRT; q++) N[q] = TAIL ? tail[q] : 0u;
     };
-    auto from_bytes = [&](const u32 (&w)[NW], u32 (&N)[NRT]) {     // all-zero bytes are the state of a path that starts here
-        unpack_n<NRT>(w, N);
+    auto from_bytes = [&](const u32 (&w)[SWN], u32 (&N)[NRT]) {    // all-zero words are the state of a path that starts here
+        if constexpr (S16) {
+#pragma unroll
+            for (int q = 0; q < NRT; q++) N[q] = w[q];
+        } else unpack_n<NRT>(w, N);
         if (TAIL) {
 #pragma unroll
             for (int q = 0; q < NRT; q++) N[q] |= tail[q];
@@ -245,9 +255,9 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     fetch(0);
     // states of the row above kept in registers: the vertical one for one step, the diagonal one for two.  The loop is
     // unrolled by two so that "keep" is a matter of which register set a step names, not of copies.
-    u32 V0[NW], V1[NW], DA[NW], DB[NW];
+    u32 V0[SWN], V1[SWN], DA[SWN], DB[SWN];
 #pragma unroll
-    for (int q = 0; q < NW; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; }
+    for (int q = 0; q < SWN; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; }
     __syncthreads();                   // the communication wave has parked pixel 0 and pixel 1 of the row above
     if (j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
         lds_get(&hin[0][0][lic * 4], V0);
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
     __syncthreads();
     // one step: Vuse was read in the previous step, D two steps ago; Vfill / D receive what the row above published in
     // the previous step (D only after its old contents have been consumed)
-    auto step = [&](int t, u32 (&Vuse)[NW], u32 (&Vfill)[NW], u32 (&D)[NW]) {
+    auto step = [&](int t, u32 (&Vuse)[SWN], u32 (&Vfill)[SWN], u32 (&D)[SWN]) {
         const int u = t - 2 * j;
         const bool active = rowOk && u >= 0 && u < W;
         const int x = xf;
@@ -272,14 +282,14 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
         fetch(t + 1);
         const u32* above = aboveBase + ((t + 1) & 1) * aboveStride;
         lds_get(above, Vfill);
-        u32 curA[NW];
+        u32 curA[SWN];
         lds_get(above + 2 * SW, curA);                  // anti-diagonal: used at once
         if (active) {
             // paths that start at this pixel (image border): rare, so the per-lane selects sit behind a wave-level test
             const bool firstCol = u == 0, lastCol = u == W - 1;
             if (__any(top || firstCol || lastCol)) {
 #pragma unroll
-                for (int q = 0; q < NW; q++) {
+                for (int q = 0; q < SWN; q++) {
                     if (top || lastCol) curA[q] = 0;
                     if (top) Vuse[q] = 0;
                     if (top || firstCol) D[q] = 0;
@@ -290,28 +300,36 @@ __global__ __launch_bounds__(NT + 64, (LPC == 16 && NRT == 16) ? 2 : 4) void sgm
             else step_lazy_n<LPC, NRT>(Nh, ooh, C, P1P1, P2P2, L, lic);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = SECOND ? pkadd(Sacc[q], L[q]) : L[q];
-            u32 N[NRT], ow[NW];
+            u32 N[NRT], ow[SWN];
+            auto path_step = [&](u32 (&Nq)[NRT]) {          // consumes the predecessor state, leaves L' in L and the new state in ow
+                if constexpr (S16) {
+                    step_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, lic);
+#pragma unroll
+                    for (int q = 0; q < NRT; q++) ow[q] = Nq[q];
+                } else step_pack_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, ow, lic);
+            };
             from_bytes(curA, N);
-            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
+            path_step(N);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             lds_put(&st[t & 1][j][2][lic * 4], ow);
             from_bytes(Vuse, N);
-            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
+            path_step(N);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             lds_put(&st[t & 1][j][0][lic * 4], ow);
             from_bytes(D, N);
-            step_pack_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic);
+            path_step(N);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             lds_put(&st[t & 1][j][1][lic * 4], ow);
             if (!SECOND) {
-                if (S4B) {
-                    pack_n<NRT>(Sacc, ow);
+                if constexpr (S4B) {
+                    u32 sw4[NW];
+                    pack_n<NRT>(Sacc, sw4);
 #pragma unroll
                     for (int q = 0; q < PL; q++)
-                        store16_stream(Srow + (size_t)x * DP + q * LPC * 16, make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]));
+                        store16_stream(Srow + (size_t)x * DP + q * LPC * 16, make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
                 } else {
 #pragma unroll
                     for (int q = 0; q < NRT / 4; q++)
@@ -365,6 +383,24 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role,
     return MDISP_OK;
 }
 
+// 16-bit path states: 16 lanes x 16 disparities only, down sweep first
+int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role, bool tail)
+{
+    const dim3 g((unsigned)nbands * ra.batch);
+#define SGM3_ROLE16(UPV, ROLEV)                                                                           \
+    do {                                                                                                  \
+        if (tail) sgm3_rows_kernel<UPV, ROLEV, true, false, 16, 8, 256, true><<<g, 256 + 64, 0, s>>>(ra);   \
+        else sgm3_rows_kernel<UPV, ROLEV, false, false, 16, 8, 256, true><<<g, 256 + 64, 0, s>>>(ra);       \
+    } while (0)
+    if (!up && role == 0) SGM3_ROLE16(false, 0);
+    else if (up && role == 1) SGM3_ROLE16(true, 1);
+    else if (up && role == 2) SGM3_ROLE16(true, 2);
+    else MD_REQUIRE(false, MDISP_E_UNSUPPORTED, "row bands: this sweep order is not built for 16-bit path states");
+#undef SGM3_ROLE16
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
 }  // namespace
 
 // geometry of the row-band kernels: a pixel has lpc lanes x dpl disparity slots; compute lanes per workgroup (512 slots
@@ -373,9 +409,11 @@ int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : 256;
 // bands of the image: one more than the rows need, because the mirrored sweep pads its first band so that band edges fall
 // on the same image rows in both directions
 int md_sgm3_bands(int H, int lpc, int nt) { const int rows = nt / lpc; return (H + rows - 1) / rows; }
-size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt) { return md_align((size_t)(md_sgm3_bands(H, lpc, nt) + 1) * W * 3 * lpc * dpl, 256); }
+// bytes of the path states that cross a band edge (three states per pixel; s16: 16-bit states)
+size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl, bool s16) { return (size_t)W * 3 * lpc * dpl * (s16 ? 2 : 1); }
+size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt, bool s16)
+{ return md_align((size_t)(md_sgm3_bands(H, lpc, nt) + 1) * md_sgm3_boundary_bytes(W, lpc, dpl, s16), 256); }
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * (md_sgm3_bands(H, lpc, nt) + 1)) * sizeof(int), 256); }
-size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl) { return (size_t)W * 3 * lpc * dpl; }
 
 // Logical bands of one sweep that cover the image rows [r0, r1) (r0 a multiple of the band height, r1 a multiple or H)
 void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke)
@@ -390,7 +428,7 @@ void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb
 // u16 in natural order) and the winner-take-all records.  The sweep's ticket and progress words in `sync` must be zero,
 // except the progress word of band0 - 1, which must hold W when that band's states were put into `hand` from outside.
 int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                  bool s4b, bool up, int role, int band0, int nbands)
+                  bool s4b, bool up, int role, int band0, int nbands, bool s16)
 {
     RowArgs ra;
     ra.a = a; ra.hand = hand; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
@@ -404,6 +442,10 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     const bool tail = a.tail != 0;
     MD_REQUIRE(nt == md_sgm3_lanes(lpc, dpl) && (dpl == 16 || dpl == 32), MDISP_E_BADARG, "row bands: unsupported geometry");
     MD_REQUIRE(band0 >= 0 && nbands >= 1 && band0 + nbands <= ra.nb, MDISP_E_BADARG, "row bands: band range outside the image");
+    if (s16) {
+        MD_REQUIRE(lpc == 16 && dpl == 16 && !s4b, MDISP_E_UNSUPPORTED, "row bands: 16-bit path states need 16 lanes x 16 disparities");
+        return launch_rows16(s, ra, nbands, up, role, tail);
+    }
     if (dpl == 32) {
         if (lpc == 16) return launch_rows<16, 16, 128, true>(s, ra, nbands, up, role, s4b, tail);
         MD_REQUIRE(false, MDISP_E_BADARG, "row bands: unsupported geometry");
@@ -415,8 +457,8 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
 
 // Both sweeps over all bands of `batch` pairs (down first); `sync` must be zero.
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                   int naturalOut, bool s4b)
+                   int naturalOut, bool s4b, bool s16)
 {
-    MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1));
-    return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1);
+    MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1, s16));
+    return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1, s16);
 }
