@@ -75,6 +75,61 @@ def measured_issue_bound():
             "source": os.path.relpath(files[-1], ROOT)}
 
 
+def side_path(args):
+    """Side measurements of the other device-resident paths (one GPU, one pair per call: what their callers do).  The
+    headline line is `--path sgm`; these print the same kind of line so that they can be recorded next to it."""
+    import torch
+    from cameracalibration_amd import _lib, api
+    lib = _lib.load()
+    tstream = torch.cuda.Stream()
+    ctx = _lib.Context(device=0, stream=tstream.cuda_stream)
+    if args.path == "stereosgbm":
+        h, w, d = H, W, args.disp
+        mode = 1 if args.paths == 8 and args.hh else 0
+        prm = api.StereoSGBM_create(0, d, 7, 490, 1960, 1, 63, 10, 100, 32, mode)
+        L, R, _ = api.synth_pair(0x5EED0001, h, w, d)
+        dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        out = torch.empty((h, w), dtype=torch.int16, device="cuda")
+        nb = lib.mdisp_stereosgbm_workspace_bytes(h, w, 1, C.byref(prm))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        workload = (f"{w}x{h} D={d} cv::StereoSGBM replacement (Birchfield-Tomasi block 7, "
+                    f"{'MODE_HH' if mode else 'MODE_SGBM'}, median + speckle filter), one pair per call")
+        alg = 4.0 * w * h * d + 8.0 * w * h
+
+        def step():
+            _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), h, w, 1, w, C.byref(prm), out.data_ptr(), ws.data_ptr(), nb))
+    else:
+        h, w, d = 480, 640, 64
+        prm = _lib.mdisp_param(7, 0, d - 1, 1)
+        L, R, _ = api.synth_pair(0x5EED0001, h, w, d)
+        dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        out = torch.empty((h, w), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        workload = f"{w}x{h} D={d} census + 7x7 box + WTA, one pair per call"
+        alg = 2.0 * w * h + 8.0 * w * h          # the views in, the double map out: the cost volume never leaves the CU
+
+        def step():
+            _lib.check(lib.mdisp_census_stereo_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), h, w, w, C.byref(prm), api.BASIC_CENSUS, api.AGG_BOX,
+                                                   out.data_ptr()))
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    per = elapsed / args.steps
+    print(json.dumps({
+        "metric": f"Mdisp/s (WxHxD per sec) at {w}x{h}, D={d}", "value": w * h * d / per / 1e6, "unit": "Mdisp/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "s16" if args.path == "stereosgbm" else "u16", "data": "synthetic",
+        "config": {"workload": workload, "path": args.path},
+        "roofline": {"bound": "hbm", "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_pair": alg}}), flush=True)
+
+
 def main():
     global D, P2
     ap = argparse.ArgumentParser()
@@ -90,6 +145,10 @@ def main():
                     help="scheduling override for side measurements, e.g. SGM_LANES16=1 or SGM_PIPELINE=1 (mdisp_tuning_set)")
     ap.add_argument("--P2", type=int, default=P2, help="SGM penalty P2 (32 is the headline configuration; values above 247 select "
                                                       "16-bit path states)")
+    ap.add_argument("--path", default="sgm", choices=["sgm", "stereosgbm", "census_box"],
+                    help="sgm: the headline configuration; stereosgbm / census_box: side measurements of the cv::StereoSGBM "
+                         "replacement at 1920x1080 and of census + box + WTA at 640x480 (one GPU, one pair per call)")
+    ap.add_argument("--hh", action="store_true", help="--path stereosgbm: MODE_HH (eight directions) instead of MODE_SGBM")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the "
                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -104,6 +163,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    if args.path != "sgm":
+        if world > 1:
+            raise SystemExit("--path %s is a one-GPU side measurement" % args.path)
+        torch.cuda.set_device(0)
+        side_path(args)
+        return
     if args.backend != "nccl":
         local_rank %= torch.cuda.device_count()        # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
