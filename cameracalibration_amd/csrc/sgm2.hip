@@ -940,7 +940,8 @@ size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b, bool s16);
 int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                  bool s4b, bool up, int role, int band0, int nbands, bool s16);
+                  bool s4b, bool up, int role, int band0, int nbands, bool s16, int ticket);
+int md_sgm3_ring();
 size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl, bool s16);
 void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke);
 
@@ -960,7 +961,7 @@ static Sgm2Layout sgm2_layout(const md_sgm_plan& pl, int batch)
     l.cw = CW;
     l.nstrips = (pl.W + l.cw - 1) / l.cw;
     if (l.mode == SGM2_SHEAR) { l.oneB = 0; l.bndBytes = shear_hand_bytes(pl.H, pl.W, l.lpc, 256); }   // hand-off rows (sized for the narrower strips)
-    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), !l.u8m); }   // last-row states of every band
+    else if (l.mode == SGM2_ROWS) { l.oneB = 0; l.bndBytes = 2 * md_sgm3_hand_bytes(pl.H, pl.W, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), !l.u8m); }   // hand-off rings of the two sweep directions
     else { l.oneB = md_align((size_t)pl.H * l.nstrips * 256 * sizeof(u16), 256); l.bndBytes = 4 * l.oneB; }   // four border-state planes
     l.oneH = l.mode == SGM2_ROWS ? 0 : md_align((size_t)pl.H * pl.W * l.slots * (l.u8m ? 1 : 2), 256);
     l.oneRec = md_align((size_t)pl.H * pl.W * sizeof(uint2), 256);
@@ -1079,19 +1080,20 @@ int md_sgm2_rows_sweep(hipStream_t s, const md_sgm_plan& pl, const u8* cL, const
     md_sgm3_band_range(pl.H, l.lpc, nt, up, r0, r1, &kb, &ke);
     MD_REQUIRE(kb == 0 || bndIn, MDISP_E_BADARG, "rows [%d, %d) do not start at the image edge in this direction: boundary states needed", r0, r1);
     const size_t bnd = md_sgm3_boundary_bytes(pl.W, l.lpc, l.dpl, false);
-    u8* hand = extra;
+    const int ring = md_sgm3_ring();
+    u8* hand = extra + (up ? l.bndBytes / 2 : 0);
     int* sync = (int*)(extra + l.bndBytes + 2 * l.oneH + l.oneRec);
     int* prog = sync + 16 + (up ? nb : 0);           // this direction's progress words (one pair)
     MD_HIP(hipMemsetAsync(sync + (up ? 1 : 0), 0, sizeof(int), s));
     MD_HIP(hipMemsetAsync(prog, 0, (size_t)nb * sizeof(int), s));
     if (kb > 0) {
-        MD_HIP(hipMemcpyAsync(hand + (size_t)(kb - 1) * bnd, bndIn, bnd, hipMemcpyDeviceToDevice, s));
+        MD_HIP(hipMemcpyAsync(hand + (size_t)((kb - 1) & (ring - 1)) * bnd, bndIn, bnd, hipMemcpyDeviceToDevice, s));
         MD_HIP(hipMemsetD32Async((hipDeviceptr_t)(prog + kb - 1), pl.W, 1, s));     // "the row above is complete"
     }
     if (usedErrWord) *usedErrWord = true;
     const bool s4b = 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-    MD_TRY(md_sgm3_sweep(s, a, hand, l.bndBytes, sync, errWord, 1, l.lpc, l.dpl, nt, s4b, up, second ? 1 : 0, kb, ke - kb, false));
-    if (bndOut && ke < nb) MD_HIP(hipMemcpyAsync(bndOut, hand + (size_t)(ke - 1) * bnd, bnd, hipMemcpyDeviceToDevice, s));
+    MD_TRY(md_sgm3_sweep(s, a, hand, l.bndBytes, sync, errWord, 1, l.lpc, l.dpl, nt, s4b, up, second ? 1 : 0, kb, ke - kb, false, -1));
+    if (bndOut && ke < nb) MD_HIP(hipMemcpyAsync(bndOut, hand + (size_t)((ke - 1) & (ring - 1)) * bnd, bnd, hipMemcpyDeviceToDevice, s));
     if (second) {
         LrArgs l2;
         l2.rec = a.rec; l2.strideRec = a.strideRec; l2.H = pl.H; l2.W = pl.W; l2.D = pl.D; l2.minD = pl.minD;
@@ -1160,7 +1162,31 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
         }
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
-        MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, md_sgm3_lanes(l.lpc, l.dpl), naturalOut, s4b, !l.u8m));
+        const int nt = md_sgm3_lanes(l.lpc, l.dpl), rows = nt / l.lpc, nb = md_sgm3_bands(pl.H, l.lpc, nt);
+        const int meetMax = md_tune(MDISP_TUNE_SGM_MEET_MAX) >= 0 ? md_tune(MDISP_TUNE_SGM_MEET_MAX) : 4;
+        if (batch <= meetMax && aux && !naturalOut && l.u8m && l.lpc == 16 && nb >= 4) {
+            // A few pairs cannot fill the GPU and the bands of a pair follow each other 2 * rows + 3 steps apart: start
+            // from both image edges at once.  The down sweep runs first over the upper half while the up sweep runs first
+            // over the lower half (each stores its four-path sum); then each continues into the other half as the second
+            // sweep, starting from the states the other left in its hand-off ring -- the critical path of a pair is one
+            // sweep over the image instead of two.
+            const int hb = nb / 2, r0 = hb * rows;        // image rows [0, r0) and [r0, H)
+            int kbd, ked, kbu, keu;
+            md_sgm3_band_range(pl.H, l.lpc, nt, false, 0, r0, &kbd, &ked);        // down over the upper half: bands [0, ked)
+            md_sgm3_band_range(pl.H, l.lpc, nt, true, r0, pl.H, &kbu, &keu);      // up over the lower half:   bands [0, keu)
+            u8* handDown = extra; u8* handUp = extra + l.bndBytes / 2;
+            hipStream_t s2 = aux->aux;
+            MD_HIP(hipEventRecord(aux->ev[0], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[0], 0));
+            MD_TRY(md_sgm3_sweep(s, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 0, 0, ked, false, 0));
+            MD_TRY(md_sgm3_sweep(s2, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 0, 0, keu, false, 1));
+            MD_HIP(hipEventRecord(aux->ev[1], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[1], 0));
+            MD_HIP(hipEventRecord(aux->ev[2], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[2], 0));
+            MD_TRY(md_sgm3_sweep(s, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 1, keu, nb - keu, false, 2));
+            MD_TRY(md_sgm3_sweep(s2, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 1, ked, nb - ked, false, 3));
+            MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0));
+        } else {
+            MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, naturalOut, s4b, !l.u8m));
+        }
     } else if (l.mode == SGM2_SHEAR) {
         ShearArgs sa;
         sa.a = a;

@@ -30,7 +30,7 @@ namespace {
 
 struct RowArgs {
     Sgm2Args a;
-    u8* hand;               // [B][nb][W][3][slots bytes]: states (v, \, /) of the last row of every band, per pixel
+    u8* hand;               // [B][ring][W][3][state bytes]: states (v, \, /) of the last row of a band, per pixel; band b uses entry b & ringMask
     size_t strideHand;      // bytes per pair
     int* sync;              // [0] ticket (down) [1] ticket (up), [16 + (sweep*B + pair)*nb + band] pixels published by the band's last row
     int* err;               // sticky error word (owned by the caller)
@@ -38,6 +38,8 @@ struct RowArgs {
     int band0;              // first band this launch runs (its predecessor's states and progress word are already in place)
     int nbands;             // bands this launch runs
     int group;              // pairs dispatched together: tickets run band-major inside a group of pairs, group after group
+    int ringMask;           // entries of the hand-off ring - 1 (a power of two: an entry is rewritten only by a band that started after its reader finished with it)
+    int ticket;             // which of the ticket words in sync[0..15] this launch counts on
     int slack;              // pixels a band stays behind its predecessor beyond the two it needs
     int vofs;               // logical rows of band 0 that lie before the image (so that band edges fall on the same image rows in both directions)
 };
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * NRT : 1];
     __shared__ u32 exclMask[FUSE ? DPLn + 3 : 1][NRT];
     __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[UP ? 1 : 0], 1);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
     if (FUSE) init_excl_mask_n<NRT>(exclMask);
     __syncthreads();
     const int ticket = s_ticket;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
         int* errWord = ra.err;
         int seen = 0;
         const __amdgpu_buffer_rsrc_t rsrc = hand_rsrc(hand, ra.strideHand);      // the pair's rows: below 4 GB
-        auto hand_slot = [&](int bnd, int u, int wh) -> u32 { return (u32)((((size_t)bnd * W + u) * 3 + wh) * DPB + lic * 16); };
+        auto hand_slot = [&](int bnd, int u, int wh) -> u32 { return (u32)((((size_t)(bnd & ra.ringMask) * W + u) * 3 + wh) * DPB + lic * 16); };
         // slot 0 consumes in step i (i >= -1) the states of pixel i + 1 of the row above
         auto wants = [&](int i) -> bool { return hasPrev && which < 3 && i + 1 < W; };
         auto request = [&](int i, u32 (&w)[SWN]) {
@@ -411,8 +413,17 @@ int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : 256;
 int md_sgm3_bands(int H, int lpc, int nt) { const int rows = nt / lpc; return (H + rows - 1) / rows; }
 // bytes of the path states that cross a band edge (three states per pixel; s16: 16-bit states)
 size_t md_sgm3_boundary_bytes(int W, int lpc, int dpl, bool s16) { return (size_t)W * 3 * lpc * dpl * (s16 ? 2 : 1); }
+// The hand-off rows of one pair and one sweep direction: a ring of entries indexed by band & (entries - 1).  Band b + 1
+// reads entry b pixel by pixel before it publishes the same pixel of its own last row, and so on down the chain, so by
+// the time band b + entries writes a pixel of the entry every reader of the old contents is past it: two entries would
+// do; 32 keep neighbouring bands in different cache sets and the whole ring below the 4 GB a buffer descriptor spans.
+int md_sgm3_ring()
+{
+    const int e = md_tune(MDISP_TUNE_SGM_HAND_RING);
+    return e >= 2 ? (e >= 32 ? 32 : e >= 16 ? 16 : e >= 8 ? 8 : e >= 4 ? 4 : 2) : 32;
+}
 size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt, bool s16)
-{ return md_align((size_t)(md_sgm3_bands(H, lpc, nt) + 1) * md_sgm3_boundary_bytes(W, lpc, dpl, s16), 256); }
+{ (void)H; (void)nt; return md_align((size_t)md_sgm3_ring() * md_sgm3_boundary_bytes(W, lpc, dpl, s16), 256); }
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * (md_sgm3_bands(H, lpc, nt) + 1)) * sizeof(int), 256); }
 
 // Logical bands of one sweep that cover the image rows [r0, r1) (r0 a multiple of the band height, r1 a multiple or H)
@@ -428,7 +439,7 @@ void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb
 // u16 in natural order) and the winner-take-all records.  The sweep's ticket and progress words in `sync` must be zero,
 // except the progress word of band0 - 1, which must hold W when that band's states were put into `hand` from outside.
 int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
-                  bool s4b, bool up, int role, int band0, int nbands, bool s16)
+                  bool s4b, bool up, int role, int band0, int nbands, bool s16, int ticket)
 {
     RowArgs ra;
     ra.a = a; ra.hand = hand; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
@@ -437,6 +448,9 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     ra.vofs = up ? ra.nb * rows - a.H : 0;
     if (nbands < 0) nbands = ra.nb - band0;
     ra.nbands = nbands;
+    ra.ringMask = md_sgm3_ring() - 1;
+    ra.ticket = ticket >= 0 ? ticket : (up ? 1 : 0);
+    MD_REQUIRE(strideHand < ((size_t)1 << 32) && ra.ticket < 16, MDISP_E_RANGE, "row bands: hand-off ring of %zu bytes per pair exceeds 4 GB", strideHand);
     { const int g = md_tune(MDISP_TUNE_SGM_PAIR_GROUP); ra.group = g > 0 ? std::min(g, batch) : batch; }
     { const int sl = md_tune(MDISP_TUNE_SGM_BAND_SLACK); ra.slack = sl > 0 ? sl : 0; }
     const bool tail = a.tail != 0;
@@ -455,10 +469,10 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     return launch_rows<16, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
 }
 
-// Both sweeps over all bands of `batch` pairs (down first); `sync` must be zero.
+// Both sweeps over all bands of `batch` pairs (down first); `sync` must be zero.  The two sweeps may share one hand-off ring.
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b, bool s16)
 {
-    MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1, s16));
-    return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1, s16);
+    MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1, s16, -1));
+    return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1, s16, -1);
 }

@@ -196,8 +196,11 @@ SGM_CASES = [
 # streams + summing winner-take-all; for one pair the three paths of a sweep on three groups of waves, "latency, one
 # wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
 # with the strip width of small batches (512 lanes per workgroup) or of large ones (256); "row bands" = the pipeline of
-# row bands with four paths per sweep that batches of eight-path problems take
-@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands"])
+# row bands with four paths per sweep that batches of eight-path problems take (one sweep after the other, as batches run
+# them); "row bands, both edges" = the row bands of a few pairs, whose sweeps start from both image edges at once;
+# "row bands, ring of two" = the same with the smallest hand-off ring, so that entries are reused many times
+@pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands", "row bands, both edges",
+                        "row bands, ring of two"])
 def sgm_schedule(request):
     from cameracalibration_amd import _lib
     _lib.tuning_reset()
@@ -205,6 +208,10 @@ def sgm_schedule(request):
         _lib.tuning_set(_lib.TUNE_SGM_PATH_WAVES_MAX, 0)
     elif request.param.startswith("row bands"):
         _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
+        if request.param == "row bands":
+            _lib.tuning_set(_lib.TUNE_SGM_MEET_MAX, 0)
+        if "ring" in request.param:
+            _lib.tuning_set(_lib.TUNE_SGM_HAND_RING, 2)
     elif request.param != "latency":
         _lib.tuning_set(_lib.TUNE_SGM_SPLIT_MAX, 0)
         _lib.tuning_set(_lib.TUNE_SGM_PIPELINE, 1)

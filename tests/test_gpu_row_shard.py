@@ -38,6 +38,21 @@ CASES = [
 
 @pytest.mark.parametrize("H,W,D,minD,P2,world", CASES)
 def test_row_sharded_pair_equals_the_single_call(H, W, D, minD, P2, world):
+    _run_case(H, W, D, minD, P2, world)
+
+
+def test_row_sharded_pair_with_the_smallest_hand_off_ring():
+    """Hand-off entries (and the entry a boundary is delivered into) are reused every second band."""
+    from cameracalibration_amd import _lib
+    _lib.tuning_reset()
+    _lib.tuning_set(_lib.TUNE_SGM_HAND_RING, 2)
+    try:
+        _run_case(150, 130, 200, 0, 32, 3)
+    finally:
+        _lib.tuning_reset()
+
+
+def _run_case(H, W, D, minD, P2, world):
     import torch
     from cameracalibration_amd import _lib, api, shard
     lib = _lib.load()
