@@ -220,6 +220,55 @@ def sgm_schedule(request):
     _lib.tuning_reset()
 
 
+BATCH_CASES = [
+    # B, H, W, pitch, D, minD, P2, tuning
+    (9, 70, 150, 150, 256, 0, 32, {}),                          # row bands, several pairs per band level
+    (9, 70, 150, 150, 256, 0, 32, {"SGM_PAIR_GROUP": 4}),       # pairs dispatched in groups, the last group partial
+    (5, 45, 300, 300, 512, 0, 32, {}),                          # 32 disparities per lane
+    (3, 90, 210, 210, 300, 2, 60, {}),                          # a few pairs at D > 256: sweeps from both image edges, 16-bit sums
+    (7, 50, 120, 120, 128, 0, 300, {}),                         # 16-bit path states on the row bands
+    (6, 40, 75, 83, 64, 1, 32, {}),                             # rows that are not dword-aligned: the census reads bytes
+    (6, 40, 76, 80, 64, 0, 32, {"SGM_PIPELINE": 1}),            # the sheared strips
+    (2, 130, 90, 92, 200, 0, 32, {"SGM_SPLIT_MAX": 0, "SGM_HAND_RING": 4}),
+]
+
+
+@pytest.mark.parametrize("B,H,W,pitch,D,minD,P2,tuning", BATCH_CASES)
+def test_sgm_batch_variants(api, orc, B, H, W, pitch, D, minD, P2, tuning):
+    """mdisp_sgbm_batch_dev (pitched device input, pair stride with slack) == the oracle on every pair."""
+    import ctypes as C
+    import torch
+    from cameracalibration_amd import _lib
+    lib = _lib.load()
+    _lib.tuning_reset()
+    for k, v in tuning.items():
+        _lib.tuning_set(getattr(_lib, "TUNE_" + k), v)
+    try:
+        params = api.sgbm_params(minD, D, 8, P2, 10, 1, 8, 1)
+        stride = pitch * H + 52                                 # pairs need not be packed (52: keeps dword alignment, breaks 16-byte alignment)
+        bufL = np.full(B * stride, 0xAB, np.uint8)
+        bufR = np.full(B * stride, 0xCD, np.uint8)
+        Ls, Rs = [], []
+        for i in range(B):
+            L, R = rand_pair(1000 + 7 * i + H, H, W, min(D, W))
+            Ls.append(L)
+            Rs.append(R)
+            bufL[i * stride:i * stride + pitch * H].reshape(H, pitch)[:, :W] = L
+            bufR[i * stride:i * stride + pitch * H].reshape(H, pitch)[:, :W] = R
+        dl, dr = torch.from_numpy(bufL).cuda(), torch.from_numpy(bufR).cuda()
+        out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ctx = _lib.Context()
+        _lib.check(lib.mdisp_sgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), B, stride, H, W, pitch, C.byref(params),
+                                            out.data_ptr(), None, 0))
+        ctx.synchronize()
+        got = out.cpu().numpy()
+        for i in range(B):
+            assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], minD, D, 8, P2, 10, 1, 8, 1)), f"pair {i}"
+    finally:
+        _lib.tuning_reset()
+
+
 @pytest.mark.parametrize("case", SGM_CASES)
 def test_sgm_bit_exact(api, orc, case, sgm_schedule):
     H, W, minD, D, P1, P2, uniq, maxDiff, paths, sub = case
