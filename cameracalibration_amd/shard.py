@@ -57,12 +57,14 @@ def gather_row_bands(band, rows, dist=None):
     tall = max(row_band(rows, r, world)[1] - row_band(rows, r, world)[0] for r in range(world))
     padded = torch.zeros((tall,) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
     padded[:band.shape[0]] = band
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded)
+    # the bytes are gathered: gloo has no collectives for 16-bit integers (disparity maps are int16)
+    raw = padded.contiguous().view(torch.uint8)
+    parts = [torch.empty_like(raw) for _ in range(world)]
+    dist.all_gather(parts, raw)
     out = []
     for r in range(world):
         b, e = row_band(rows, r, world)
-        out.append(parts[r][:e - b])
+        out.append(parts[r].view(band.dtype).reshape(padded.shape)[:e - b])
     return torch.cat(out, dim=0)
 
 

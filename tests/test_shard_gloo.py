@@ -87,10 +87,13 @@ def _band_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rows, cols = 11, 5                       # odd height: the bands differ by one row
-        full = torch.arange(rows * cols, dtype=torch.float32).reshape(rows, cols)
-        b, e = shard.row_band(rows, rank, world)
-        got = shard.gather_row_bands(full[b:e].clone(), rows, dist)
-        q.put((rank, bool(torch.equal(got, full)), (b, e)))
+        ok = True
+        for dtype in (torch.float32, torch.int16, torch.float64):        # int16: disparity maps (no 16-bit integer collectives in gloo)
+            full = (torch.arange(rows * cols, dtype=torch.float32) - 20).to(dtype).reshape(rows, cols)
+            b, e = shard.row_band(rows, rank, world)
+            got = shard.gather_row_bands(full[b:e].clone(), rows, dist)
+            ok = ok and got.dtype == dtype and bool(torch.equal(got, full))
+        q.put((rank, ok, (b, e)))
     finally:
         dist.destroy_process_group()
 
