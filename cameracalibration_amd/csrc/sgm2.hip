@@ -1163,10 +1163,11 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         }
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
         const int nt = md_sgm3_lanes(l.lpc, l.dpl), rows = nt / l.lpc, nb = md_sgm3_bands(pl.H, l.lpc, nt);
-        const int meetMax = md_tune(MDISP_TUNE_SGM_MEET_MAX) >= 0 ? md_tune(MDISP_TUNE_SGM_MEET_MAX) : 4;
-        if (batch <= meetMax && aux && !naturalOut && l.u8m && l.lpc == 16 && nb >= 4) {
-            // A few pairs cannot fill the GPU and the bands of a pair follow each other 2 * rows + 3 steps apart: start
-            // from both image edges at once.  The down sweep runs first over the upper half while the up sweep runs first
+        const int meetMax = md_tune(MDISP_TUNE_SGM_MEET_MAX) >= 0 ? md_tune(MDISP_TUNE_SGM_MEET_MAX) : 1 << 30;
+        if (batch <= meetMax && aux && !naturalOut && nb >= 4) {
+            // The bands of a pair follow each other 2 * rows + 3 steps apart, so a sweep needs (bands of a pair in flight) x
+            // that many steps to fill the GPU and as many to drain it: start from both image edges at once, which halves
+            // the chain (64 pairs: 0.894 -> 0.877 ms per pair, 16 pairs: 1.51 -> 1.40, 8 pairs: 2.38 -> 1.73).  The down sweep runs first over the upper half while the up sweep runs first
             // over the lower half (each stores its four-path sum); then each continues into the other half as the second
             // sweep, starting from the states the other left in its hand-off ring -- the critical path of a pair is one
             // sweep over the image instead of two.
@@ -1177,12 +1178,12 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             u8* handDown = extra; u8* handUp = extra + l.bndBytes / 2;
             hipStream_t s2 = aux->aux;
             MD_HIP(hipEventRecord(aux->ev[0], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[0], 0));
-            MD_TRY(md_sgm3_sweep(s, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 0, 0, ked, false, 0));
-            MD_TRY(md_sgm3_sweep(s2, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 0, 0, keu, false, 1));
+            MD_TRY(md_sgm3_sweep(s, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 0, 0, ked, !l.u8m, 0));
+            MD_TRY(md_sgm3_sweep(s2, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 0, 0, keu, !l.u8m, 1));
             MD_HIP(hipEventRecord(aux->ev[1], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[1], 0));
             MD_HIP(hipEventRecord(aux->ev[2], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[2], 0));
-            MD_TRY(md_sgm3_sweep(s, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 1, keu, nb - keu, false, 2));
-            MD_TRY(md_sgm3_sweep(s2, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 1, ked, nb - ked, false, 3));
+            MD_TRY(md_sgm3_sweep(s, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 1, keu, nb - keu, !l.u8m, 2));
+            MD_TRY(md_sgm3_sweep(s2, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 1, ked, nb - ked, !l.u8m, 3));
             MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0));
         } else {
             MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, naturalOut, s4b, !l.u8m));

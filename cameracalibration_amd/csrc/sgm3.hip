@@ -385,7 +385,7 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role,
     return MDISP_OK;
 }
 
-// 16-bit path states: 16 lanes x 16 disparities only, down sweep first
+// 16-bit path states: 16 lanes x 16 disparities only
 int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role, bool tail)
 {
     const dim3 g((unsigned)nbands * ra.batch);
@@ -397,6 +397,8 @@ int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int rol
     if (!up && role == 0) SGM3_ROLE16(false, 0);
     else if (up && role == 1) SGM3_ROLE16(true, 1);
     else if (up && role == 2) SGM3_ROLE16(true, 2);
+    else if (up && role == 0) SGM3_ROLE16(true, 0);
+    else if (!up && role == 1) SGM3_ROLE16(false, 1);
     else MD_REQUIRE(false, MDISP_E_UNSUPPORTED, "row bands: this sweep order is not built for 16-bit path states");
 #undef SGM3_ROLE16
     MD_HIP(hipGetLastError());
@@ -464,8 +466,8 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
         if (lpc == 16) return launch_rows<16, 16, 128, true>(s, ra, nbands, up, role, s4b, tail);
         MD_REQUIRE(false, MDISP_E_BADARG, "row bands: unsupported geometry");
     }
-    if (lpc == 4) return launch_rows<4, 8, 256, false>(s, ra, nbands, up, role, s4b, tail);
-    if (lpc == 8) return launch_rows<8, 8, 256, false>(s, ra, nbands, up, role, s4b, tail);
+    if (lpc == 4) return launch_rows<4, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
+    if (lpc == 8) return launch_rows<8, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
     return launch_rows<16, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
 }
 

@@ -439,7 +439,7 @@ enum {
     MDISP_TUNE_SGM_BAND_SLACK = 9,     /* row bands: pixels a band stays behind its predecessor beyond the minimum  */
     MDISP_TUNE_SGM_PAIR_GROUP = 10,    /* row bands: pairs whose bands are dispatched together (band-major inside a group) */
     MDISP_TUNE_SGM_HAND_RING = 11,     /* row bands: entries of the hand-off ring (2..32, a power of two; default 32) */
-    MDISP_TUNE_SGM_MEET_MAX = 12,      /* row bands: largest batch whose two sweeps start from both image edges at once (default 4) */
+    MDISP_TUNE_SGM_MEET_MAX = 12,      /* row bands: largest batch whose two sweeps start from both image edges at once (default: any) */
     MDISP_TUNE_COUNT = 13
 };
 int mdisp_tuning_set(int key, int value);

@@ -196,8 +196,8 @@ SGM_CASES = [
 # streams + summing winner-take-all; for one pair the three paths of a sweep on three groups of waves, "latency, one
 # wave group" forces the kernel that two or three pairs get), "pipeline" = the sheared strip pipeline that batches use,
 # with the strip width of small batches (512 lanes per workgroup) or of large ones (256); "row bands" = the pipeline of
-# row bands with four paths per sweep that batches of eight-path problems take (one sweep after the other, as batches run
-# them); "row bands, both edges" = the row bands of a few pairs, whose sweeps start from both image edges at once;
+# row bands with four paths per sweep that batches of eight-path problems take, here one sweep after the other;
+# "row bands, both edges" = the row bands as batches run them: both sweeps start at once, each from its image edge;
 # "row bands, ring of two" = the same with the smallest hand-off ring, so that entries are reused many times
 @pytest.fixture(params=["latency", "latency, one wave group", "pipeline", "pipeline, narrow strips", "row bands", "row bands, both edges",
                         "row bands, ring of two"])
@@ -230,6 +230,10 @@ BATCH_CASES = [
     (6, 40, 75, 83, 64, 1, 32, {}),                             # rows that are not dword-aligned: the census reads bytes
     (6, 40, 76, 80, 64, 0, 32, {"SGM_PIPELINE": 1}),            # the sheared strips
     (2, 130, 90, 92, 200, 0, 32, {"SGM_SPLIT_MAX": 0, "SGM_HAND_RING": 4}),
+    (9, 70, 150, 150, 256, 0, 32, {"SGM_MEET_MAX": 0}),         # one sweep after the other instead of both edges at once
+    (6, 70, 140, 140, 96, 0, 32, {}),                           # eight lanes per pixel, both edges
+    (6, 75, 100, 100, 48, 3, 32, {}),                           # four lanes per pixel, both edges, masked tail
+    (7, 80, 120, 120, 128, 0, 300, {"SGM_MEET_MAX": 0}),        # 16-bit path states, one sweep after the other
 ]
 
 
