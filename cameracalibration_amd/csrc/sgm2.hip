@@ -896,6 +896,7 @@ static int path_waves_max_batch()
 }
 static int sgm2_mode(const md_sgm_plan& pl)
 {
+    if (pl.npaths == 4) return SGM2_ROWS;             // the two horizontal and the two vertical paths: row bands without the diagonal steps
     const bool rowsWanted = pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1;
     if (!fits_u8(pl))      // 16-bit path states: row bands for batches, upright strips + pre-pass for a few pairs
         return rowsWanted && pl.batch > split_max_batch() && md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) <= 0 ? SGM2_ROWS : SGM2_PREPASS;
@@ -918,7 +919,7 @@ static int lanes_per_pixel(const md_sgm_plan& pl)
 {
     const int mode = sgm2_mode(pl);
     if (rows_wide_lanes(pl)) return pl.D > 256 ? 16 : 8;
-    if (pl.rowBands || (mode == SGM2_ROWS && !fits_u8(pl))) return 16;      // row-sharded calls, 16-bit path states: one geometry
+    if (pl.rowBands || (mode == SGM2_ROWS && (!fits_u8(pl) || pl.npaths == 4))) return 16;      // row-sharded calls, 16-bit path states: one geometry
     if ((mode != SGM2_SHEAR && mode != SGM2_ROWS) || md_tune(MDISP_TUNE_SGM_LANES16) > 0) return 16;
     return pl.D <= 64 ? 4 : pl.D <= 128 ? 8 : 16;
 }
@@ -978,7 +979,7 @@ size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
 {
-    return (pl.npaths == 8 || (pl.npaths == 5 && fits_u8(pl))) && (pl.D <= 256 || (pl.npaths == 8 && fits_u8(pl))) && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
+    return (pl.npaths == 8 || pl.npaths == 4 || (pl.npaths == 5 && fits_u8(pl))) && (pl.D <= 256 || (pl.npaths == 8 && fits_u8(pl))) && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 
@@ -1040,6 +1041,7 @@ static void sgm2_fill_args(const md_sgm_plan& pl, const Sgm2Layout& l, const u8*
     a.tail = pl.D < l.slots;
     a.naturalOut = naturalOut;
     a.five = pl.npaths == 5;
+    a.four = pl.npaths == 4;
     a.byteSum = (pl.npaths == 5 ? 2 : 5) * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
     a.rec = (uint2*)(hbase + 2 * l.oneH * batch);
     a.strideRec = l.oneRec / sizeof(uint2);

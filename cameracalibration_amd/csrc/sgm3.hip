@@ -53,7 +53,8 @@ struct RowArgs {
 // second sweep with the full sum exported in natural disparity order.  Either direction can be the first sweep.
 // S16: the three states that leave the registers travel as 16-bit values (path values that do not fit a byte: 8 + P2 >
 // 255) -- twice the LDS and hand-off bytes, no pack / unpack.
-template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false>
+// FOUR: the 4-path mode (horizontal + vertical paths only): the two diagonal steps are left out.
+template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
 __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
 {
     constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     u32 tail[NRT];
     make_tail_n<NRT>(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
+    constexpr bool four = FOUR;
     auto fresh = [&](u32 (&N)[NRT]) {
 #pragma unroll
         for (int q = 0; q < NRT; q++) N[q] = TAIL ? tail[q] : 0u;
@@ -310,21 +312,25 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                     for (int q = 0; q < NRT; q++) ow[q] = Nq[q];
                 } else step_pack_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, ow, lic);
             };
-            from_bytes(curA, N);
-            path_step(N);
+            if constexpr (!four) {
+                from_bytes(curA, N);
+                path_step(N);
 #pragma unroll
-            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            lds_put(&st[t & 1][j][2][lic * 4], ow);
+                for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+                lds_put(&st[t & 1][j][2][lic * 4], ow);
+            }
             from_bytes(Vuse, N);
             path_step(N);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
             lds_put(&st[t & 1][j][0][lic * 4], ow);
-            from_bytes(D, N);
-            path_step(N);
+            if constexpr (!four) {
+                from_bytes(D, N);
+                path_step(N);
 #pragma unroll
-            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            lds_put(&st[t & 1][j][1][lic * 4], ow);
+                for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+                lds_put(&st[t & 1][j][1][lic * 4], ow);
+            }
             if (!SECOND) {
                 if constexpr (S4B) {
                     u32 sw4[NW];
@@ -363,16 +369,16 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     if (t < T) step(t, V0, V1, DA);
 }
 
-template <int LPC, int NRT, int NT, bool BOTH>
+template <int LPC, int NRT, int NT, bool BOTH, bool FOUR = false>
 int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role, bool s4b, bool tail)
 {
     const dim3 g((unsigned)nbands * ra.batch);
 #define SGM3_ROLE(UPV, ROLEV)                                                                                 \
     do {                                                                                                      \
-        if (tail) { if (s4b) sgm3_rows_kernel<UPV, ROLEV, true, true, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);   \
-                    else sgm3_rows_kernel<UPV, ROLEV, true, false, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra); }    \
-        else { if (s4b) sgm3_rows_kernel<UPV, ROLEV, false, true, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra);       \
-               else sgm3_rows_kernel<UPV, ROLEV, false, false, LPC, NRT, NT><<<g, NT + 64, 0, s>>>(ra); }        \
+        if (tail) { if (s4b) sgm3_rows_kernel<UPV, ROLEV, true, true, LPC, NRT, NT, false, FOUR><<<g, NT + 64, 0, s>>>(ra);   \
+                    else sgm3_rows_kernel<UPV, ROLEV, true, false, LPC, NRT, NT, false, FOUR><<<g, NT + 64, 0, s>>>(ra); }    \
+        else { if (s4b) sgm3_rows_kernel<UPV, ROLEV, false, true, LPC, NRT, NT, false, FOUR><<<g, NT + 64, 0, s>>>(ra);       \
+               else sgm3_rows_kernel<UPV, ROLEV, false, false, LPC, NRT, NT, false, FOUR><<<g, NT + 64, 0, s>>>(ra); }        \
     } while (0)
     if (!up && role == 0) SGM3_ROLE(false, 0);
     else if (up && role == 1) SGM3_ROLE(true, 1);
@@ -386,13 +392,14 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role,
 }
 
 // 16-bit path states: 16 lanes x 16 disparities only
+template <bool FOUR>
 int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role, bool tail)
 {
     const dim3 g((unsigned)nbands * ra.batch);
 #define SGM3_ROLE16(UPV, ROLEV)                                                                           \
     do {                                                                                                  \
-        if (tail) sgm3_rows_kernel<UPV, ROLEV, true, false, 16, 8, 256, true><<<g, 256 + 64, 0, s>>>(ra);   \
-        else sgm3_rows_kernel<UPV, ROLEV, false, false, 16, 8, 256, true><<<g, 256 + 64, 0, s>>>(ra);       \
+        if (tail) sgm3_rows_kernel<UPV, ROLEV, true, false, 16, 8, 256, true, FOUR><<<g, 256 + 64, 0, s>>>(ra);   \
+        else sgm3_rows_kernel<UPV, ROLEV, false, false, 16, 8, 256, true, FOUR><<<g, 256 + 64, 0, s>>>(ra);       \
     } while (0)
     if (!up && role == 0) SGM3_ROLE16(false, 0);
     else if (up && role == 1) SGM3_ROLE16(true, 1);
@@ -460,11 +467,15 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     MD_REQUIRE(band0 >= 0 && nbands >= 1 && band0 + nbands <= ra.nb, MDISP_E_BADARG, "row bands: band range outside the image");
     if (s16) {
         MD_REQUIRE(lpc == 16 && dpl == 16 && !s4b, MDISP_E_UNSUPPORTED, "row bands: 16-bit path states need 16 lanes x 16 disparities");
-        return launch_rows16(s, ra, nbands, up, role, tail);
+        return a.four ? launch_rows16<true>(s, ra, nbands, up, role, tail) : launch_rows16<false>(s, ra, nbands, up, role, tail);
     }
     if (dpl == 32) {
         if (lpc == 16) return launch_rows<16, 16, 128, true>(s, ra, nbands, up, role, s4b, tail);
         MD_REQUIRE(false, MDISP_E_BADARG, "row bands: unsupported geometry");
+    }
+    if (a.four) {
+        MD_REQUIRE(lpc == 16 && dpl == 16, MDISP_E_UNSUPPORTED, "row bands: the 4-path mode is built for 16 lanes x 16 disparities");
+        return launch_rows<16, 8, 256, true, true>(s, ra, nbands, up, role, s4b, tail);
     }
     if (lpc == 4) return launch_rows<4, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
     if (lpc == 8) return launch_rows<8, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);

@@ -30,6 +30,7 @@ struct Sgm2Args {
     u16* S2; int splitUp;                 // split mode: the up sweep does not read S and stores its own four-path sum here
     uint2* rec; size_t strideRec;         // fused WTA output, one record per pixel [B][H][W]
     int bias, uniq;                       // npaths*P2 and the uniqueness ratio (percent)
+    int four;                             // 4-path mode (the two horizontal and the two vertical paths): the row-band sweeps skip their diagonal paths
     int smallS;                           // every aggregated cost, times the disparities per lane, stays below 0x7C00 (row-band winner-take-all)
 };
 // WTA record: x = minS' | (best d << 16) | (not-unique << 31),  y = S'(best-1) | (S'(best+1) << 16)

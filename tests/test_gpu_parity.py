@@ -186,6 +186,9 @@ SGM_CASES = [
     (30, 350, 0, 257, 8, 247, 10, 1, 8, 0),     # ... just above 256, largest P2 with byte path states
     (45, 300, 0, 200, 8, 32, 10, 1, 8, 1),      # sixteen lanes with a masked tail
     (45, 300, 0, 129, 8, 100, 10, 1, 8, 1),     # ... just above 128, 16-bit four-path sums
+    (60, 130, 1, 256, 8, 32, 10, 1, 4, 1),      # four paths (horizontal + vertical): row bands without the diagonal steps
+    (40, 210, 0, 200, 5, 300, 10, 1, 4, 1),      # ... with 16-bit path states and a masked tail
+    (44, 90, 0, 48, 8, 32, 10, 2, 4, 0),        # ... few disparities (still sixteen lanes per pixel: most of them masked)
     (70, 200, 0, 256, 8, 300, 10, 1, 8, 1),     # 16-bit path states: row bands with 16-bit hand-off (batches), upright strips (latency)
     (50, 160, 2, 200, 20, 500, 10, 1, 8, 1),    # ... with a masked tail, close to the largest P2 (8 * (8 + P2) < 4096)
     (33, 90, 0, 128, 8, 248, 5, 2, 8, 0),       # ... the smallest P2 whose path values leave the byte range
