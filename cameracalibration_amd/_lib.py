@@ -58,7 +58,7 @@ EXPORTS = [
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev", "mdisp_sgbm_rows_geometry", "mdisp_sgbm_rows_sweep_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
-    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity",
+    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity", "mdisp_ncc",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
     "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
@@ -127,6 +127,7 @@ def load():
     lib.mdisp_remap_with.argtypes = [vp, vp, img, img]
     lib.mdisp_remap_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     lib.mdisp_legacy_disparity.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, img]
+    lib.mdisp_ncc.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_int, C.c_int, img, vp]
     lib.mdisp_sgbm_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, sgp, vp, C.c_int]
     lib.mdisp_sgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, sgp, vp, vp, C.c_size_t]
     lib.mdisp_sgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, sgp]

@@ -564,8 +564,32 @@ def _legacy(method, leftImg, rightImg, winSize, threshold_T, minDisparity, numDi
     return out
 
 
+DISPARITY_LEFT, DISPARITY_RIGHT = 0, 1          # methods/parametersStereo.h:5-9
+
+
 class stereomatch_1:
     """The reference's namespace of the same name: same function names, argument order and defaults."""
+
+    @staticmethod
+    def computeNCC(leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=0, numDisparity=30, ctx=None, cost_ds=None):
+        """Both overloads of computeNCC (methods/method_StereoMatching.h:116-120).  Without `cost_ds` the float32 map is
+        returned (None where the reference returns an empty image); with `cost_ds` (a list) the list is cleared and
+        receives numDisparity normalised float32 slices, and nothing is returned."""
+        L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+        if L.shape[:2] != R.shape[:2] or winSize % 2 == 0:
+            return None
+        H, W = L.shape[:2]
+        if cost_ds is None:
+            out = np.empty((H, W), np.float32)
+            check(load().mdisp_ncc(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), 1 if dispType == DISPARITY_LEFT else 0, winSize,
+                                   minDisparity, numDisparity, C.byref(image(out)), None))
+            return out
+        vol = np.empty((numDisparity, H, W), np.float32)
+        check(load().mdisp_ncc(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), 1 if dispType == DISPARITY_LEFT else 0, winSize,
+                               minDisparity, numDisparity, None, vol.ctypes.data))
+        del cost_ds[:]
+        cost_ds.extend(vol[k] for k in range(numDisparity))
+        return None
 
     @staticmethod
     def computeAD(leftImg, rightImg, minDisparity=0, numDisparity=30, ctx=None):

@@ -306,7 +306,7 @@ struct Carver {
 
 // Upload an 8-bit image as single-channel gray (checkImg, methods_disp.cpp:130-147: 3-channel
 // input goes through COLOR_BGR2GRAY).  `stage` is device scratch for the interleaved BGR rows.
-static int upload_gray(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch, u8* stage, size_t stage_pitch)
+static int upload_gray(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch, u8* stage, size_t stage_pitch, int rgbOrder = 0)
 {
     MD_REQUIRE(im->depth == MDISP_8U, MDISP_E_UNSUPPORTED, "only CV_8U images are supported (got depth %d)", im->depth);
     if (im->channels == 1) {
@@ -315,7 +315,7 @@ static int upload_gray(mdisp_ctx* c, const mdisp_image* im, u8* d, size_t dpitch
     }
     MD_REQUIRE(im->channels == 3, MDISP_E_UNSUPPORTED, "only 1- or 3-channel images are supported");
     MD_TRY(md_h2d_2d(c, stage, stage_pitch, im->data, im->step_bytes, (size_t)im->cols * 3, im->rows));
-    return md_bgr2gray(c->stream, stage, stage_pitch, im->rows, im->cols, d, dpitch);
+    return md_bgr2gray(c->stream, stage, stage_pitch, im->rows, im->cols, d, dpitch, rgbOrder);
 }
 
 static int census_arg_for(int method, int winSize, int leftBranch)
@@ -820,6 +820,37 @@ extern "C" int mdisp_legacy_disparity(mdisp_ctx* c, const mdisp_image* L, const 
     if ((rc = md_legacy_disparity(c->stream, base + o_l, pitch, base + o_r, pitch, H, W, method, winSize, T, minD, numD, base + o_d, pitch)))
         return rc;
     MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, pitch, W, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+// stereomatch_1::computeNCC: the map (out, CV_32F) and / or the normalised cost volume (cost, numDisparity slices of rows*cols floats)
+extern "C" int mdisp_ncc(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, int is_left, int winSize, int minD, int numD,
+                         mdisp_image* out, float* cost)
+{
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    int rc;
+    if ((rc = check_image(L, "left")) || (rc = check_image(R, "right"))) return rc;
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    MD_REQUIRE(out || cost, MDISP_E_BADARG, "nothing to compute: pass a map, a cost volume or both");
+    MD_REQUIRE(winSize >= 1 && winSize % 2 == 1, MDISP_E_BADARG, "winSize must be odd");
+    MD_REQUIRE(numD >= 1 && minD >= 0 && (long)L->cols + minD + numD <= 65535, MDISP_E_BADARG, "disparity range");
+    if (out && (rc = check_out(out, L->rows, L->cols, MDISP_32F, 1, "out"))) return rc;
+    MD_HIP(hipSetDevice(c->device));
+    const int H = L->rows, W = L->cols;
+    const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256), N = (size_t)H * W;
+    Carver cv;
+    const size_t o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_st = cv.take(p3 * H), o_ws = cv.take(md_ncc_bytes(H, W, minD, numD)),
+                 o_d = cv.take(N * 4), o_c = cv.take(cost ? N * 4 * numD : 0);
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    // the reference converts colour input with COLOR_RGB2GRAY (method_StereoMatching.cpp:934-942): the first channel is weighted as red
+    if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3, 1))) return rc;
+    if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3, 1))) return rc;
+    MD_TRY(md_ncc(c->stream, base + o_l, base + o_r, pitch, H, W, is_left != 0, winSize, minD, numD, base + o_ws,
+                  out ? (float*)(base + o_d) : nullptr, cost ? (float*)(base + o_c) : nullptr));
+    if (out) MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 4, (size_t)W * 4, H));
+    if (cost) MD_HIP(hipMemcpyAsync(cost, base + o_c, N * 4 * numD, hipMemcpyDeviceToHost, c->stream));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;
 }

@@ -231,14 +231,16 @@ __global__ __launch_bounds__(256) void hamming_kernel(const u8* __restrict__ a, 
     dst[(size_t)y * (dp / 4) + x] = __popc((u32)(a[(size_t)y * ap + x] ^ b[(size_t)y * bp + x]));
 }
 
-// OpenCV 8-bit BGR2GRAY: (B*1868 + G*9617 + R*4899 + 2^13) >> 14
+// OpenCV 8-bit BGR2GRAY: (B*1868 + G*9617 + R*4899 + 2^13) >> 14; rgbOrder: COLOR_RGB2GRAY, which reads the first
+// channel as red (what stereomatch_1::computeNCC applies to its BGR input)
 __global__ __launch_bounds__(256) void bgr2gray_kernel(const u8* __restrict__ bgr, size_t sp, int H, int W,
-                                                       u8* __restrict__ gray, size_t dp)
+                                                       u8* __restrict__ gray, size_t dp, int rgbOrder)
 {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const u8* p = bgr + (size_t)y * sp + 3 * x;
-    gray[(size_t)y * dp + x] = (u8)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+    const int b = rgbOrder ? p[2] : p[0], r = rgbOrder ? p[0] : p[2];
+    gray[(size_t)y * dp + x] = (u8)((b * 1868 + p[1] * 9617 + r * 4899 + (1 << 13)) >> 14);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -410,10 +412,10 @@ int md_hamming(hipStream_t s, const u8* a, size_t ap, const u8* b, size_t bp, in
     return MDISP_OK;
 }
 
-int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch)
+int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch, int rgbOrder)
 {
     dim3 grid((W + 255) / 256, H);
-    bgr2gray_kernel<<<grid, 256, 0, s>>>(bgr, spitch, H, W, gray, dpitch);
+    bgr2gray_kernel<<<grid, 256, 0, s>>>(bgr, spitch, H, W, gray, dpitch, rgbOrder);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }

@@ -75,6 +75,10 @@ __host__ __device__ static inline int md_align_dev(int v, int a) { return (v + a
 
 // ---- kernels' host launchers (all enqueue on `s`, no sync) ----
 // census.hip
+// ncc.hip
+size_t md_ncc_bytes(int H, int W, int minD, int numD);
+int md_ncc(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int isLeft, int win, int minD, int numD, void* ws,
+           float* dOut, float* dCost);
 int md_census_pairs(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, size_t pairStride, int batch, int H, int W, int left, int method,
                     u8* cL, size_t pitchL, size_t strideL, u8* cR, size_t pitchR, size_t strideR);
 int md_pad_reflect_lr(hipStream_t s, const u8* src, size_t spitch, int H, int W, int left, int right, u8* dst, size_t dpitch);
@@ -82,7 +86,7 @@ int md_census(hipStream_t s, const u8* src, size_t spitch, int H, int W, int met
               u8* scratch /* H*dpitch (rounded up to 256) + MD_CENSUS_SCRATCH_TAIL bytes, needed by the MULTISCALE variants */);
 #define MD_CENSUS_SCRATCH_TAIL 2048
 int md_hamming(hipStream_t s, const u8* a, size_t ap, const u8* b, size_t bp, int H, int W, int32_t* dst, size_t dp);
-int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch);
+int md_bgr2gray(hipStream_t s, const u8* bgr, size_t spitch, int H, int W, u8* gray, size_t dpitch, int rgbOrder = 0);
 
 // sgm.hip
 struct md_sgm_plan {

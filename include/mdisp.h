@@ -238,6 +238,20 @@ int mdisp_filter_speckles_s16(mdisp_ctx*, mdisp_image* img, int newVal, int maxS
 int mdisp_legacy_disparity(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, int method, int winSize,
                            int threshold_T, int minDisparity, int numDisparity, mdisp_image* out);
 
+/* stereomatch_1::computeNCC (methods/method_StereoMatching.cpp:871-1106; declarations method_StereoMatching.h:115-120).
+ * left/right CV_8UC1 or 3-channel (converted with COLOR_RGB2GRAY as the reference does: the first channel is weighted as
+ * red); numDisparity is a COUNT.  The score is sum(l.*r) / (sum(l.*l) * sum(r.*r)) over winSize x winSize windows of the
+ * REFLECT-padded view minus the REFLECT_101 box mean -- the reference's expression, product of energies included.
+ *   out  (CV_32F, or NULL): the map overload.  is_left: offsets minDisparity .. minDisparity + numDisparity - 2 (the
+ *        reference never tries the last one), the strictly smallest score wins, 0 where none was accepted.  The
+ *        reference's right map is never assigned (it compares with "> DBL_MAX") and returns uninitialised memory: here
+ *        it is all zeros.
+ *   cost (host floats numDisparity x rows x cols, or NULL): the cost-volume overload, every offset, every slice
+ *        normalised to [0, 1] (cv::normalize NORM_MINMAX), for both map types.
+ * An even winSize or a size mismatch fails with MDISP_E_BADARG (the reference returns an empty result). */
+int mdisp_ncc(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, int is_left, int winSize, int minDisparity,
+              int numDisparity, mdisp_image* out, float* cost);
+
 /* LR consistency check of PatchMatch::postProcess, methods/patchmatch.cpp:817-828.
  * dL/dR CV_32F, validL/validR CV_8U (1 = consistent within `thresh`). */
 int mdisp_lr_check(mdisp_ctx*, const mdisp_image* dL, const mdisp_image* dR, float thresh,

@@ -138,7 +138,20 @@ inline void getRectifiedImages(cv::Mat imgLeft, cv::Mat imgRight, std::string ca
 }
 
 // methods/method_StereoMatching.h:94-112 (namespace stereomatch_1): the fixed-window matchers on cv::Mat
+#ifndef MDISP_CV_NO_DISPARITY_TYPE      // define it when methods/parametersStereo.h (the same enum, :5-9) is included as well
+using mdisp::stereomatch_1::DisparityType;
+using mdisp::stereomatch_1::DISPARITY_LEFT;
+using mdisp::stereomatch_1::DISPARITY_RIGHT;
+#define MDISP_CV_DISPARITY_LEFT DISPARITY_LEFT
+#else
+#define MDISP_CV_DISPARITY_LEFT ((DisparityType)0)
+#endif
 namespace stereomatch_1 {
+inline cv::Mat computeNCC(cv::Mat l, cv::Mat r, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
+{ return mdisp::stereomatch_1::computeNCC(l, r, (mdisp::stereomatch_1::DisparityType)(int)dispType, winSize, minDisparity, numDisparity); }
+inline void computeNCC(cv::Mat l, cv::Mat r, std::vector<cv::Mat>& cost_ds, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, int winSize = 7,
+                       int minDisparity = 0, int numDisparity = 30)
+{ mdisp::stereomatch_1::computeNCC(l, r, cost_ds, (mdisp::stereomatch_1::DisparityType)(int)dispType, winSize, minDisparity, numDisparity); }
 inline cv::Mat computeAD(cv::Mat l, cv::Mat r, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeAD(l, r, minDisparity, numDisparity); }
 inline cv::Mat computeSAD(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSAD(l, r, winSize, minDisparity, numDisparity); }
 inline cv::Mat computeSAD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSAD_inteOpti(l, r, winSize, minDisparity, numDisparity); }

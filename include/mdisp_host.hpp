@@ -475,6 +475,40 @@ template <class M> M legacy_(int method, M leftImg, M rightImg, int winSize, int
                                          numDisparity, &o));
     return out;
 }
+// computeNCC, both overloads (method_StereoMatching.h:116-120; DisparityType: parametersStereo.h:5-9).  An even window
+// or a size mismatch returns an empty image / leaves cost_ds alone, without a message, as the reference does.
+enum DisparityType { DISPARITY_LEFT = 0, DISPARITY_RIGHT = 1 };
+template <class M> M computeNCC(M leftImg, M rightImg, DisparityType dispType = DISPARITY_LEFT, int winSize = 7, int minDisparity = 0,
+                                int numDisparity = 30)
+{
+    typedef mat_traits<M> T;
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    if (l.rows != r.rows || l.cols != r.cols || winSize % 2 == 0) return M();
+    M out;
+    T::create(out, l.rows, l.cols, MDISP_32F, 1);
+    mdisp_image o = T::view(out);
+    detail::check(mdisp_ncc(Context::forThisThread().handle(), &l, &r, dispType == DISPARITY_LEFT, winSize, minDisparity, numDisparity, &o, nullptr));
+    return out;
+}
+template <class M> void computeNCC(M leftImg, M rightImg, std::vector<M>& cost_ds, DisparityType dispType = DISPARITY_LEFT, int winSize = 7,
+                                   int minDisparity = 0, int numDisparity = 30)
+{
+    typedef mat_traits<M> T;
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    if (l.rows != r.rows || l.cols != r.cols || winSize % 2 == 0) return;
+    cost_ds.clear();
+    std::vector<float> vol((size_t)numDisparity * l.rows * l.cols);
+    detail::check(mdisp_ncc(Context::forThisThread().handle(), &l, &r, dispType == DISPARITY_LEFT, winSize, minDisparity, numDisparity, nullptr,
+                            vol.data()));
+    for (int k = 0; k < numDisparity; k++) {
+        M slice;
+        T::create(slice, l.rows, l.cols, MDISP_32F, 1);
+        mdisp_image sv = T::view(slice);
+        for (int y = 0; y < l.rows; y++)
+            std::memcpy((char*)sv.data + (size_t)y * sv.step_bytes, vol.data() + ((size_t)k * l.rows + y) * l.cols, (size_t)l.cols * sizeof(float));
+        cost_ds.push_back(slice);
+    }
+}
 template <class M> M computeAD(M leftImg, M rightImg, int minDisparity = 0, int numDisparity = 30)
 { return legacy_<M>(MDISP_LEGACY_AD, leftImg, rightImg, 1, 0, minDisparity, numDisparity); }
 template <class M> M computeSAD(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)

@@ -110,6 +110,10 @@ void orc_box_sum_u32(const uint32_t* src, int H, int W, int kw, int kh, uint32_t
 void orc_normalize_minmax_u8(const uint8_t* src, long n, float* dst);
 void orc_normalize_minmax_s32(const int32_t* src, long n, float* dst);
 void orc_normalize_minmax_f32(const float* src, long n, float* dst);
+
+/* orc_ncc.c: stereomatch_1::computeNCC, map and cost-volume overloads (methods/method_StereoMatching.cpp:871-1106) */
+int orc_ncc_disparity(const uint8_t* L, const uint8_t* R, int H, int W, int is_left, int win, int minD, int numD, float* out);
+int orc_ncc_volume(const uint8_t* L, const uint8_t* R, int H, int W, int is_left, int win, int minD, int numD, float* cost);
 void orc_guided_filter(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out);
 void orc_guided_filter_egif(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out, float* beta);
 void orc_guided_filter_wgif(const float* guideN, const float* pN, int H, int W, int r, double eps, float* out);

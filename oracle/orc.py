@@ -378,6 +378,26 @@ def legacy_disparity(L, R, method, winSize=7, threshold_T=30, minDisparity=0, nu
     return None if rc else out
 
 
+def ncc_disparity(L, R, is_left=True, winSize=7, minDisparity=0, numDisparity=30):
+    """stereomatch_1::computeNCC, map overload (methods/method_StereoMatching.cpp:915-1015) -> float32, or None where the
+    reference refuses (even window)."""
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    out = np.empty((H, W), np.float32)
+    rc = lib().orc_ncc_disparity(_p(L), _p(R), H, W, 1 if is_left else 0, winSize, minDisparity, numDisparity, _p(out))
+    return None if rc else out
+
+
+def ncc_volume(L, R, is_left=True, winSize=7, minDisparity=0, numDisparity=30):
+    """stereomatch_1::computeNCC, cost-volume overload (methods/method_StereoMatching.cpp:1017-1106) -> float32
+    [numDisparity, H, W], every slice normalised to [0, 1]."""
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    out = np.empty((numDisparity, H, W), np.float32)
+    rc = lib().orc_ncc_volume(_p(L), _p(R), H, W, 1 if is_left else 0, winSize, minDisparity, numDisparity, _p(out))
+    return None if rc else out
+
+
 def bm_prefilter_xsobel(img, cap=31):
     img = _u8(img)
     out = np.empty_like(img)

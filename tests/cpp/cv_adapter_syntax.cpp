@@ -1,6 +1,7 @@
 // Compile-only check of include/mdisp_cv.hpp against the OpenCV test double in tests/cpp/fake_cv: the adapter is
 // included twice (the include guard must cover the whole file) and every boundary function is named once so that
 // its body and the templates behind it are instantiated.
+#include <vector>
 #include "mdisp_cv.hpp"
 #include "mdisp_cv.hpp"
 
@@ -25,4 +26,7 @@ void use_every_boundary_function(cv::Mat l, cv::Mat r, std::string xml)
     a = stereomatch_1::computeSAD_BFOpti(l, r); a = stereomatch_1::computeTAD(l, r); a = stereomatch_1::computeSTAD(l, r);
     a = stereomatch_1::computeSTAD_inteOpti(l, r); a = stereomatch_1::computeSTAD_BFOpti(l, r); a = stereomatch_1::computeSD(l, r);
     a = stereomatch_1::computeSSD(l, r); a = stereomatch_1::computeSSD_inteOpti(l, r); a = stereomatch_1::computeSSD_BFOpti(l, r);
+    std::vector<cv::Mat> slices;
+    a = stereomatch_1::computeNCC(l, r); a = stereomatch_1::computeNCC(l, r, DISPARITY_RIGHT, 5, 2, 16);
+    stereomatch_1::computeNCC(l, r, slices); stereomatch_1::computeNCC(l, r, slices, DISPARITY_LEFT, 7, 0, 30);
 }

@@ -66,6 +66,11 @@ int main(int argc, char** argv)
     Mat dLeg = stereomatch_1::computeSSD_BFOpti(L, R, 7, 0, maxD + 1);                                        // method_StereoMatching.h:112
     if (dLeg.empty()) return fail("empty stereomatch_1 output");
     std::fwrite(dLeg.data(), 1, (size_t)H * W, f);
+    Mat dNcc = stereomatch_1::computeNCC(L, R, stereomatch_1::DISPARITY_LEFT, 5, 0, 8);                       // method_StereoMatching.h:116-117
+    std::vector<Mat> nccSlices;
+    stereomatch_1::computeNCC(L, R, nccSlices, stereomatch_1::DISPARITY_RIGHT, 5, 1, 4);                      // method_StereoMatching.h:118-120
+    if (dNcc.empty() || nccSlices.size() != 4 || !stereomatch_1::computeNCC(L, R, stereomatch_1::DISPARITY_LEFT, 4).empty())
+        return fail("computeNCC: empty output, wrong slice count, or an even window accepted");
     // cv::StereoBM the way methods.cpp:1829-1838 drives it (smaller range and window), and the stereoMatching() dispatcher
     Mat dBm, dDispatch;
     StereoBM sbm = StereoBM::create(16, 9);

@@ -48,3 +48,53 @@ def test_legacy_error_behaviour(api):
         api.stereomatch_1.computeAD(img, img, 2, 16)                    # the reference's ROI would leave the image
     bgr = np.dstack([img, img, img])
     assert api.stereomatch_1.computeSAD_BFOpti(bgr, bgr, 5, 0, 8).shape == (20, 30)
+
+
+# ---- stereomatch_1::computeNCC (methods/method_StereoMatching.cpp:871-1106) ----------------------------------------
+# The HIP path sums in the oracle's order (row-major over the window, float products, double sums), so the values agree
+# bit for bit: the map is compared exactly, the normalised volume to 1e-6 (its scale is rounded to float once).
+
+@pytest.mark.parametrize("shape,win,minD,numD", [((24, 50), 5, 0, 12), ((30, 41), 7, 2, 9), ((17, 33), 3, 0, 30), ((12, 20), 9, 1, 5),
+                                                ((20, 36), 1, 0, 6)])
+def test_ncc_map_matches_the_oracle(api, orc, shape, win, minD, numD):
+    L, R = rand_pair(shape[0] * 13 + shape[1] + win, shape[0], shape[1], min(numD, 8))
+    got = api.stereomatch_1.computeNCC(L, R, api.DISPARITY_LEFT, win, minD, numD)
+    exp = orc.ncc_disparity(L, R, True, win, minD, numD)
+    assert got.dtype == np.float32 and got.shape == L.shape
+    assert np.array_equal(got, exp)
+    if win > 1:       # a 1x1 window is its own mean: every score is 0/0 and no offset is ever accepted
+        assert got.min() >= minD and got.max() <= minD + numD - 2     # the last offset is never tried
+    # the reference never assigns the right map (it compares with "> DBL_MAX"): zeros here
+    right = api.stereomatch_1.computeNCC(L, R, api.DISPARITY_RIGHT, win, minD, numD)
+    assert np.array_equal(right, np.zeros_like(right)) and np.array_equal(right, orc.ncc_disparity(L, R, False, win, minD, numD))
+
+
+@pytest.mark.parametrize("left", [True, False])
+@pytest.mark.parametrize("shape,win,minD,numD", [((24, 50), 5, 0, 12), ((19, 37), 7, 3, 6)])
+def test_ncc_cost_volume_matches_the_oracle(api, orc, left, shape, win, minD, numD):
+    L, R = rand_pair(shape[0] * 5 + shape[1] + numD, shape[0], shape[1], min(numD, 8))
+    slices = ["stale"]
+    api.stereomatch_1.computeNCC(L, R, api.DISPARITY_LEFT if left else api.DISPARITY_RIGHT, win, minD, numD, cost_ds=slices)
+    exp = orc.ncc_volume(L, R, left, win, minD, numD)
+    assert len(slices) == numD                                      # the list is cleared first, every offset gets a slice
+    got = np.stack(slices)
+    assert np.isfinite(got).all() and np.isfinite(exp).all()
+    assert np.abs(got - exp).max() <= 1e-6
+    for k in range(numD):
+        assert got[k].min() == pytest.approx(0.0, abs=1e-6) and got[k].max() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_ncc_colour_input_and_error_behaviour(api, orc):
+    rng = np.random.default_rng(5)
+    Lc = rng.integers(0, 256, size=(18, 30, 3), dtype=np.uint8)
+    Rc = rng.integers(0, 256, size=(18, 30, 3), dtype=np.uint8)
+    # COLOR_RGB2GRAY on the reference's BGR images: the FIRST channel gets the red weight (method_StereoMatching.cpp:934-942)
+    def rgb2gray(c):
+        return ((c[..., 0].astype(np.int64) * 4899 + c[..., 1].astype(np.int64) * 9617 + c[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    got = api.stereomatch_1.computeNCC(Lc, Rc, api.DISPARITY_LEFT, 5, 0, 10)
+    assert np.array_equal(got, orc.ncc_disparity(rgb2gray(Lc), rgb2gray(Rc), True, 5, 0, 10))
+    assert api.stereomatch_1.computeNCC(Lc[..., 0], Rc[..., 0], api.DISPARITY_LEFT, 4, 0, 10) is None       # even window: empty result
+    assert api.stereomatch_1.computeNCC(Lc[..., 0], Rc[:10, :, 0], api.DISPARITY_LEFT, 5, 0, 10) is None    # size mismatch
+    keep = ["kept"]
+    api.stereomatch_1.computeNCC(Lc[..., 0], Rc[..., 0], api.DISPARITY_LEFT, 6, 0, 10, cost_ds=keep)
+    assert keep == ["kept"]                                          # the reference returns before it clears the list
