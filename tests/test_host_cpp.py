@@ -42,7 +42,7 @@ def test_cv_adapter_names_every_boundary_function():
     for name in ("computeSAD_inteOpti", "computeSAD_BFOpti", "censusStereo", "asw_gifs", "countCensusImg", "countHummingDist",
                  "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "getGuidedFilter_ours_gif", "getGuidedFilter_ours_gif2",
                  "getGuidedFilter_ours_gif3", "steerFilter",
-                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam"):
+                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam", "computeNCC"):
         assert name in text
 
 
