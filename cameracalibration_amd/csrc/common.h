@@ -99,6 +99,7 @@ struct md_sgm_plan {
     bool use_v2;      // strip-fused two-sweep aggregation (sgm2.hip) instead of per-direction scans
     int sstride;      // u16 elements per pixel in the S volume
     bool rowBands;    // the row-band schedule whatever the batch size (row-sharded calls)
+    bool exportVolume; // the caller wants the full 16-bit sums, not disparity maps
 };
 // second stream + fork/join events of a context (created on first use); null members = run everything on one stream
 struct md_aux_streams { hipStream_t aux; hipEvent_t ev[3]; };

@@ -246,6 +246,7 @@ static const int DIRS[8][2] = {{+1, 0}, {-1, 0}, {0, +1}, {0, -1}, {+1, +1}, {-1
 int md_sgm_plan_make(int H, int W, const mdisp_sgbm_params* p, int batch, md_sgm_plan* plan, bool exportVolume, bool rowBands)
 {
     plan->rowBands = false;
+    plan->exportVolume = exportVolume;
     MD_REQUIRE(batch >= 1 && batch <= 4096, MDISP_E_BADARG, "batch must be in 1..4096");
     plan->batch = batch;
     MD_REQUIRE(p && plan, MDISP_E_BADARG, "null SGM parameters");

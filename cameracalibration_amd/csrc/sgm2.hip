@@ -897,6 +897,8 @@ static int path_waves_max_batch()
 static int sgm2_mode(const md_sgm_plan& pl)
 {
     if (pl.npaths == 4) return SGM2_ROWS;             // the two horizontal and the two vertical paths: row bands without the diagonal steps
+    if (pl.npaths == 5 && !pl.exportVolume && (!fits_u8(pl) || (md_tune(MDISP_TUNE_SGM_PIPELINE) != 1 && pl.batch > split_max_batch())))
+        return SGM2_ROWS;                             // four paths in one sweep + the opposite horizontal path with the winner-take-all
     const bool rowsWanted = pl.npaths == 8 && md_tune(MDISP_TUNE_SGM_PIPELINE) != 1;
     if (!fits_u8(pl))      // 16-bit path states: row bands for batches, upright strips + pre-pass for a few pairs
         return rowsWanted && pl.batch > split_max_batch() && md_tune(MDISP_TUNE_SGM_FORCE_PREPASS) <= 0 ? SGM2_ROWS : SGM2_PREPASS;
@@ -979,7 +981,7 @@ size_t md_sgm2_extra_bytes(const md_sgm_plan& pl, int batch)
 
 bool md_sgm2_supported(const md_sgm_plan& pl)
 {
-    return (pl.npaths == 8 || pl.npaths == 4 || (pl.npaths == 5 && fits_u8(pl))) && (pl.D <= 256 || (pl.npaths == 8 && fits_u8(pl))) && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
+    return (pl.npaths == 8 || pl.npaths == 4 || (pl.npaths == 5 && (fits_u8(pl) || !pl.exportVolume))) && (pl.D <= 256 || (pl.npaths == 8 && fits_u8(pl))) && pl.costWin == 1 && (long)pl.npaths * (8 + pl.P2) < 4096 && pl.P1 < 2048 &&
            pl.maxD - pl.minD + 1 == pl.D && pl.uniq <= 100;
 }
 
@@ -1166,7 +1168,13 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
         const int nt = md_sgm3_lanes(l.lpc, l.dpl), rows = nt / l.lpc, nb = md_sgm3_bands(pl.H, l.lpc, nt);
         const int meetMax = md_tune(MDISP_TUNE_SGM_MEET_MAX) >= 0 ? md_tune(MDISP_TUNE_SGM_MEET_MAX) : 1 << 30;
-        if (batch <= meetMax && aux && !naturalOut && nb >= 4) {
+        if (a.five) {
+            // the four paths that run with the rows in one sweep, then the opposite horizontal path (no dependency between
+            // rows) added to the stored sum, with the winner-take-all
+            MD_REQUIRE(!naturalOut, MDISP_E_UNSUPPORTED, "five paths on the row bands: no volume export");
+            MD_TRY(md_sgm3_sweep(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 0, 0, -1, !l.u8m, 0));
+            MD_TRY(md_sgm3_sweep(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 3, 0, -1, !l.u8m, 1));
+        } else if (batch <= meetMax && aux && !naturalOut && nb >= 4) {
             // The bands of a pair follow each other 2 * rows + 3 steps apart, so a sweep needs (bands of a pair in flight) x
             // that many steps to fill the GPU and as many to drain it: start from both image edges at once, which halves
             // the chain (64 pairs: 0.894 -> 0.877 ms per pair, 16 pairs: 1.51 -> 1.40, 8 pairs: 2.38 -> 1.73).  The down sweep runs first over the upper half while the up sweep runs first

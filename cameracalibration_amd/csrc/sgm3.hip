@@ -50,14 +50,16 @@ struct RowArgs {
 // across the pixel's lanes.
 // UP: the sweep's direction (false: top to bottom, left to right; true: mirrored).  ROLE: 0 = the first sweep over the
 // rows (stores the four-path sum), 1 = the second sweep (adds the stored sum, runs the winner-take-all), 2 = the
-// second sweep with the full sum exported in natural disparity order.  Either direction can be the first sweep.
+// second sweep with the full sum exported in natural disparity order, 3 = the last sweep of the five-path mode: only
+// the path along the row (no dependency between rows: no hand-off, no barriers), added to the stored four-path sum,
+// then the winner-take-all.  Either direction can be the first sweep.
 // S16: the three states that leave the registers travel as 16-bit values (path values that do not fit a byte: 8 + P2 >
 // 255) -- twice the LDS and hand-off bytes, no pack / unpack.
 // FOUR: the 4-path mode (horizontal + vertical paths only): the two diagonal steps are left out.
 template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
 __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
 {
-    constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1;
+    constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1 || ROLE == 3, HONLY = ROLE == 3;
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, NW = NRT / 2;
     constexpr int SWN = S16 ? NRT : NRT / 2;      // dwords of one path state per lane
     constexpr int PLS = SWN / 4;                  // ... as 16-byte planes
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     };
 
     if (threadIdx.x >= NT) {
+        if (HONLY) return;      // rows are independent: nothing to exchange
         // ---- communication wave: publishes the last slot's states one step behind the compute waves and fetches
         // the states slot 0 will consume one step ahead of them
         const int lane = threadIdx.x - NT, which = lane / LPC, lic = lane % LPC;
@@ -262,12 +265,12 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     u32 V0[SWN], V1[SWN], DA[SWN], DB[SWN];
 #pragma unroll
     for (int q = 0; q < SWN; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; }
-    __syncthreads();                   // the communication wave has parked pixel 0 and pixel 1 of the row above
-    if (j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
+    if (!HONLY) __syncthreads();       // the communication wave has parked pixel 0 and pixel 1 of the row above
+    if (!HONLY && j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
         lds_get(&hin[0][0][lic * 4], V0);
         lds_get(&hin[0][1][lic * 4], DB);
     }
-    __syncthreads();
+    if (!HONLY) __syncthreads();
     // one step: Vuse was read in the previous step, D two steps ago; Vfill / D receive what the row above published in
     // the previous step (D only after its old contents have been consumed)
     auto step = [&](int t, u32 (&Vuse)[SWN], u32 (&Vfill)[SWN], u32 (&D)[SWN]) {
@@ -285,18 +288,22 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
         }
         fetch(t + 1);
         const u32* above = aboveBase + ((t + 1) & 1) * aboveStride;
-        lds_get(above, Vfill);
         u32 curA[SWN];
-        lds_get(above + 2 * SW, curA);                  // anti-diagonal: used at once
+        if constexpr (!HONLY) {
+            lds_get(above, Vfill);
+            lds_get(above + 2 * SW, curA);              // anti-diagonal: used at once
+        }
         if (active) {
             // paths that start at this pixel (image border): rare, so the per-lane selects sit behind a wave-level test
             const bool firstCol = u == 0, lastCol = u == W - 1;
             if (__any(top || firstCol || lastCol)) {
+                if constexpr (!HONLY) {
 #pragma unroll
-                for (int q = 0; q < SWN; q++) {
-                    if (top || lastCol) curA[q] = 0;
-                    if (top) Vuse[q] = 0;
-                    if (top || firstCol) D[q] = 0;
+                    for (int q = 0; q < SWN; q++) {
+                        if (top || lastCol) curA[q] = 0;
+                        if (top) Vuse[q] = 0;
+                        if (top || firstCol) D[q] = 0;
+                    }
                 }
                 if (firstCol) { fresh(Nh); ooh = 0; }
             }
@@ -312,19 +319,21 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                     for (int q = 0; q < NRT; q++) ow[q] = Nq[q];
                 } else step_pack_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, ow, lic);
             };
-            if constexpr (!four) {
+            if constexpr (!four && !HONLY) {
                 from_bytes(curA, N);
                 path_step(N);
 #pragma unroll
                 for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
                 lds_put(&st[t & 1][j][2][lic * 4], ow);
             }
-            from_bytes(Vuse, N);
-            path_step(N);
+            if constexpr (!HONLY) {
+                from_bytes(Vuse, N);
+                path_step(N);
 #pragma unroll
-            for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-            lds_put(&st[t & 1][j][0][lic * 4], ow);
-            if constexpr (!four) {
+                for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+                lds_put(&st[t & 1][j][0][lic * 4], ow);
+            }
+            if constexpr (!four && !HONLY) {
                 from_bytes(D, N);
                 path_step(N);
 #pragma unroll
@@ -358,8 +367,10 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                 for (int q = 0; q < NRT / 4; q++) dst[q] = make_uint4(nat[4 * q], nat[4 * q + 1], nat[4 * q + 2], nat[4 * q + 3]);
             }
         }
-        lds_get(above + SW, D);
-        __syncthreads();   // st[t & 1] complete before the next step reads it
+        if constexpr (!HONLY) {
+            lds_get(above + SW, D);
+            __syncthreads();   // st[t & 1] complete before the next step reads it
+        }
     };
     int t = 0;
     for (; t + 2 <= T; t += 2) {
@@ -383,6 +394,7 @@ int launch_rows(hipStream_t s, const RowArgs& ra, int nbands, bool up, int role,
     if (!up && role == 0) SGM3_ROLE(false, 0);
     else if (up && role == 1) SGM3_ROLE(true, 1);
     else if (up && role == 2) SGM3_ROLE(true, 2);
+    else if (up && role == 3) SGM3_ROLE(true, 3);
     else if (BOTH && up && role == 0) { if constexpr (BOTH) SGM3_ROLE(true, 0); }
     else if (BOTH && !up && role == 1) { if constexpr (BOTH) SGM3_ROLE(false, 1); }
     else MD_REQUIRE(false, MDISP_E_UNSUPPORTED, "row bands: this sweep order is not built for the geometry");
@@ -404,6 +416,7 @@ int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int rol
     if (!up && role == 0) SGM3_ROLE16(false, 0);
     else if (up && role == 1) SGM3_ROLE16(true, 1);
     else if (up && role == 2) SGM3_ROLE16(true, 2);
+    else if (up && role == 3) SGM3_ROLE16(true, 3);
     else if (up && role == 0) SGM3_ROLE16(true, 0);
     else if (!up && role == 1) SGM3_ROLE16(false, 1);
     else MD_REQUIRE(false, MDISP_E_UNSUPPORTED, "row bands: this sweep order is not built for 16-bit path states");

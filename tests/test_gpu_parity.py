@@ -173,7 +173,7 @@ SGM_CASES = [
     (90, 310, 0, 128, 8, 247, 10, 1, 8, 1),     # largest P2 with byte path states
     (60, 300, 0, 256, 8, 32, 10, 1, 5, 1),      # five paths (StereoSGBM's default mode): one fused down sweep
     (75, 40, 1, 20, 2, 5, 10, 1, 5, 0),
-    (50, 80, 0, 64, 20, 300, 10, 1, 5, 1),      # five paths with 16-bit path values: per-direction fallback
+    (50, 80, 0, 64, 20, 300, 10, 1, 5, 1),      # five paths with 16-bit path values: row bands with 16-bit states
     (120, 260, 0, 64, 8, 32, 10, 1, 8, 1),      # four lanes per pixel, several 64-column strips
     (90, 200, 1, 65, 8, 32, 10, 1, 8, 1),       # just above the four-lane limit: eight lanes, masked tail
     (100, 330, 0, 96, 6, 60, 10, 2, 8, 1),      # eight lanes per pixel, 16-bit four-path sums
@@ -238,6 +238,9 @@ BATCH_CASES = [
     (6, 75, 100, 100, 48, 3, 32, {}),                           # four lanes per pixel, both edges, masked tail
     (7, 80, 120, 120, 128, 0, 300, {"SGM_MEET_MAX": 0}),        # 16-bit path states, one sweep after the other
 ]
+BATCH5_CASES = [
+    (6, 70, 150, 150, 256, 0, 32), (6, 60, 140, 140, 100, 2, 32), (5, 50, 90, 90, 48, 0, 60), (6, 64, 120, 120, 128, 0, 300), (1, 40, 100, 100, 64, 0, 400),
+]
 
 
 @pytest.mark.parametrize("B,H,W,pitch,D,minD,P2,tuning", BATCH_CASES)
@@ -274,6 +277,27 @@ def test_sgm_batch_variants(api, orc, B, H, W, pitch, D, minD, P2, tuning):
             assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], minD, D, 8, P2, 10, 1, 8, 1)), f"pair {i}"
     finally:
         _lib.tuning_reset()
+
+
+@pytest.mark.parametrize("B,H,W,pitch,D,minD,P2", BATCH5_CASES)
+def test_sgm_five_path_batches(api, orc, B, H, W, pitch, D, minD, P2):
+    """Five paths on the row bands: four paths in one sweep, then the opposite horizontal path with the winner-take-all."""
+    import ctypes as C
+    import torch
+    from cameracalibration_amd import _lib
+    lib = _lib.load()
+    _lib.tuning_reset()
+    params = api.sgbm_params(minD, D, 8, P2, 10, 1, 5, 1)
+    Ls, Rs = zip(*[rand_pair(2000 + 3 * i + H, H, W, min(D, W)) for i in range(B)])
+    dl, dr = torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda()
+    out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    ctx = _lib.Context()
+    _lib.check(lib.mdisp_sgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), B, H * W, H, W, pitch, C.byref(params), out.data_ptr(), None, 0))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    for i in range(B):
+        assert np.array_equal(got[i], orc.sgm(Ls[i], Rs[i], minD, D, 8, P2, 10, 1, 5, 1)), f"pair {i}"
 
 
 @pytest.mark.parametrize("case", SGM_CASES)
