@@ -172,7 +172,11 @@ int mdisp_census_stereo(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, 
                         int census_method, int agg_mode, mdisp_image* out);
 
 /* computeSAD_inteOpti / computeSAD_BFOpti, methods_disp.h:43-44, methods_disp.cpp:207-408.
- * out: CV_8U HxW (value stored modulo 256 like the reference's .at<char>). */
+ * out: CV_8U HxW (value stored modulo 256 like the reference's .at<char>).
+ * mdisp_sad_inte sums in exact 32-bit integer tables; the reference's integral(..., CV_32F) tables (:238, :282) are
+ * exact only while their entries stay below 2^24 (a 255-valued image of more than 65793 pixels can exceed it), so on
+ * larger images the reference's own four-corner differences carry float rounding that this function does not reproduce:
+ * identical results are guaranteed below that size only.  The same holds for the stereomatch_1 *_inteOpti variants. */
 int mdisp_sad_inte(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
 int mdisp_sad_box(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
 
