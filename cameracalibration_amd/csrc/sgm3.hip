@@ -230,6 +230,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     const int aboveStride = j > 0 ? SLOTS * 3 * SW : 3 * SW;
 
     u32 Nh[NRT];                       // the path that runs along the row
+    EdgeRegs edge = {INF2, INF2};      // targets of the cross-lane shifts: their row-edge lanes stay "infinite"
     u32 ooh = 0;                       // its minimum (only where the state is kept un-normalised: no masked disparities)
     fresh(Nh);
     u32 clw = 0, rbw[NW], sbw[NW], Sn[NRT];
@@ -307,17 +308,17 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                 }
                 if (firstCol) { fresh(Nh); ooh = 0; }
             }
-            if (TAIL) step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic);
-            else step_lazy_n<LPC, NRT>(Nh, ooh, C, P1P1, P2P2, L, lic);
+            if (TAIL) step_n<TAIL, LPC, NRT>(Nh, C, P1P1, P2P2, tail, L, lic, edge);
+            else step_lazy_n<LPC, NRT>(Nh, ooh, C, P1P1, P2P2, L, lic, edge);
 #pragma unroll
             for (int q = 0; q < NRT; q++) Sacc[q] = SECOND ? pkadd(Sacc[q], L[q]) : L[q];
             u32 N[NRT], ow[SWN];
             auto path_step = [&](u32 (&Nq)[NRT]) {          // consumes the predecessor state, leaves L' in L and the new state in ow
                 if constexpr (S16) {
-                    step_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, lic);
+                    step_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, lic, edge);
 #pragma unroll
                     for (int q = 0; q < NRT; q++) ow[q] = Nq[q];
-                } else step_pack_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, ow, lic);
+                } else step_pack_n<TAIL, LPC, NRT>(Nq, C, P1P1, P2P2, tail, L, ow, lic, edge);
             };
             if constexpr (!four && !HONLY) {
                 from_bytes(curA, N);

@@ -57,12 +57,17 @@ __device__ __forceinline__ void unpack_n(const u32 (&w)[NRT / 2], u32 (&L)[NRT])
 
 // L'(d) = C(d) + min(N(d), P2, P1 + min(N(d-1), N(d+1))) for the lane's registers, and the minimum of L' over the
 // pixel's disparities (disparities masked by `tail` excluded) broadcast to both halves of the returned word
+// `edge` holds two registers that the row shifts write into.  A shift leaves the lanes without a source lane (the first /
+// last lane of a DPP row) untouched, so once those lanes hold "infinite" they keep it from call to call and the
+// registers never have to be re-initialised: the caller sets both to INF2 once and passes them to every step.
+struct EdgeRegs { u32 prev, next; };
 template <bool TAIL, int LPC, int NRT>
 __device__ __forceinline__ u32 path_values_n(const u32 (&N)[NRT], const u32 (&C)[NRT], u32 P1P1, u32 P2P2, const u32 (&tail)[NRT],
-                                             u32 (&L)[NRT], int lic)
+                                             u32 (&L)[NRT], int lic, EdgeRegs& edge)
 {
-    u32 prevL = dpp_keep<DPP_ROW_SHR1>(INF2, N[NRT - 1]);      // the previous lane's last disparity (high half of its last register)
-    u32 nextF = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);            // the next lane's first disparity (low half of its first register)
+    edge.prev = dpp_keep<DPP_ROW_SHR1>(edge.prev, N[NRT - 1]); // the previous lane's last disparity (high half of its last register)
+    edge.next = dpp_keep<DPP_ROW_SHL1>(edge.next, N[0]);       // the next lane's first disparity (low half of its first register)
+    u32 prevL = edge.prev, nextF = edge.next;
     if (LPC < 16) {   // several pixels share a DPP row: cut the shifts at the pixel's first / last lane
         prevL = lic == 0 ? INF2 : prevL;
         nextF = lic == LPC - 1 ? INF2 : nextF;
@@ -91,9 +96,10 @@ __device__ __forceinline__ u32 path_values_n(const u32 (&N)[NRT], const u32 (&C)
 
 // One step of a path whose state stays in registers: N <- L' - min L' (masked disparities stay "infinite")
 template <bool TAIL, int LPC, int NRT>
-__device__ __forceinline__ void step_n(u32 (&N)[NRT], const u32 (&C)[NRT], u32 P1P1, u32 P2P2, const u32 (&tail)[NRT], u32 (&L)[NRT], int lic)
+__device__ __forceinline__ void step_n(u32 (&N)[NRT], const u32 (&C)[NRT], u32 P1P1, u32 P2P2, const u32 (&tail)[NRT], u32 (&L)[NRT], int lic,
+                                       EdgeRegs& edge)
 {
-    const u32 mm = path_values_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, lic);
+    const u32 mm = path_values_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, lic, edge);
 #pragma unroll
     for (int r = 0; r < NRT; r++) N[r] = pksub(TAIL ? L[r] | tail[r] : L[r], mm);
 }
@@ -102,10 +108,12 @@ __device__ __forceinline__ void step_n(u32 (&N)[NRT], const u32 (&C)[NRT], u32 P
 // (broadcast to both halves): L'(d) = C(d) + min(L(d), oo + P2, P1 + min(L(d-1), L(d+1))) - oo.  Every operand of the
 // minimum is at least oo in both halves, so |m - oo| + C is one v_sad_u32 and nothing is subtracted afterwards.
 template <int LPC, int NRT>
-__device__ __forceinline__ void step_lazy_n(u32 (&N)[NRT], u32& oo, const u32 (&C)[NRT], u32 P1P1, u32 P2P2, u32 (&L)[NRT], int lic)
+__device__ __forceinline__ void step_lazy_n(u32 (&N)[NRT], u32& oo, const u32 (&C)[NRT], u32 P1P1, u32 P2P2, u32 (&L)[NRT], int lic,
+                                            EdgeRegs& edge)
 {
-    u32 prevL = dpp_keep<DPP_ROW_SHR1>(INF2, N[NRT - 1]);
-    u32 nextF = dpp_keep<DPP_ROW_SHL1>(INF2, N[0]);
+    edge.prev = dpp_keep<DPP_ROW_SHR1>(edge.prev, N[NRT - 1]);
+    edge.next = dpp_keep<DPP_ROW_SHL1>(edge.next, N[0]);
+    u32 prevL = edge.prev, nextF = edge.next;
     if (LPC < 16) {
         prevL = lic == 0 ? INF2 : prevL;
         nextF = lic == LPC - 1 ? INF2 : nextF;
@@ -138,9 +146,9 @@ __device__ __forceinline__ void step_lazy_n(u32 (&N)[NRT], u32& oo, const u32 (&
 // at least the minimum, so no borrow crosses a byte): half the subtractions.
 template <bool TAIL, int LPC, int NRT>
 __device__ __forceinline__ void step_pack_n(u32 (&N)[NRT], const u32 (&C)[NRT], u32 P1P1, u32 P2P2, const u32 (&tail)[NRT], u32 (&L)[NRT],
-                                            u32 (&outw)[NRT / 2], int lic)
+                                            u32 (&outw)[NRT / 2], int lic, EdgeRegs& edge)
 {
-    const u32 mm = path_values_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, lic);
+    const u32 mm = path_values_n<TAIL, LPC, NRT>(N, C, P1P1, P2P2, tail, L, lic, edge);
     if (TAIL) {
 #pragma unroll
         for (int r = 0; r < NRT; r++) N[r] = pksub(L[r] | tail[r], mm);

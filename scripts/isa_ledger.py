@@ -17,8 +17,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
-    "first sweep (stores the four-path sum)": "sgm3_rows_kernelILb0ELi0ELb0ELb1ELi16ELi8ELi256ELb0E",
-    "second sweep + winner-take-all": "sgm3_rows_kernelILb1ELi1ELb0ELb1ELi16ELi8ELi256ELb0E",
+    "first sweep (stores the four-path sum)": "sgm3_rows_kernelILb0ELi0ELb0ELb1ELi16ELi8ELi256ELb0ELb0EEEv",
+    "second sweep + winner-take-all": "sgm3_rows_kernelILb1ELi1ELb0ELb1ELi16ELi8ELi256ELb0ELb0EEEv",
 }
 GROUPS = [
     ("packed minimum (recursion: neighbours, three-input minimum; minimum trees of the paths and of the winner-take-all)",
