@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmdisp.so")
+# MDISP_LIB_PATH: a differently built library (kernel experiments, scripts/exp_build.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("MDISP_LIB_PATH") or os.path.join(HERE, "lib", "libmdisp.so")
 
 MDISP_8U, MDISP_8S, MDISP_16U, MDISP_16S, MDISP_32S, MDISP_32F, MDISP_64F = range(7)
 _DEPTH_OF = {np.dtype(np.uint8): MDISP_8U, np.dtype(np.int8): MDISP_8S, np.dtype(np.uint16): MDISP_16U,

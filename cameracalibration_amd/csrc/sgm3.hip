@@ -28,6 +28,12 @@
 
 namespace {
 
+// Waves per SIMD the register allocation aims at.  A workgroup is five waves on four SIMDs, so 5 waves per SIMD are four
+// workgroups per CU and 4 are three.  The kernels of the headline geometry (16 lanes x 16 disparities, byte sums, no masked
+// disparities) fit 96 registers without spilling; the others keep the larger budget.
+constexpr int sgm3_waves_per_simd(int lpc, int nrt, bool tail, bool s4b, bool s16)
+{ return (lpc == 16 && nrt == 16) || s16 ? 2 : (lpc == 16 && nrt == 8 && !tail && s4b ? 5 : 4); }
+
 struct RowArgs {
     Sgm2Args a;
     u8* hand;               // [B][ring][W][3][state bytes]: states (v, \, /) of the last row of a band, per pixel; band b uses entry b & ringMask
@@ -57,7 +63,7 @@ struct RowArgs {
 // 255) -- twice the LDS and hand-off bytes, no pack / unpack.
 // FOUR: the 4-path mode (horizontal + vertical paths only): the two diagonal steps are left out.
 template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
-__global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4) void sgm3_rows_kernel(RowArgs ra)
+__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16)) void sgm3_rows_kernel(RowArgs ra)
 {
     constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1 || ROLE == 3, HONLY = ROLE == 3;
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, NW = NRT / 2;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
     if (FUSE) init_excl_mask_n<NRT>(exclMask);
     __syncthreads();
-    const int ticket = s_ticket;
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);      // wave-uniform: pair, band and everything derived from them stay in scalar registers
     // tickets: group after group of pairs; inside a group band after band (dependency order), pair after pair
     const int perGroup = ra.group * ra.nbands, grp = ticket / perGroup, rem = ticket - grp * perGroup;
     const int gsz = min(ra.group, ra.batch - grp * ra.group);
@@ -202,10 +208,21 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     const int vc = min(max(v, 0), H - 1);                 // idle slots of the first / last band request (and drop) a valid row
     const int y = UP ? H - 1 - vc : vc;
     const bool top = v == 0;
-    const u8* cLrow = a.cL + (size_t)pair * a.strideL + (size_t)y * a.pL;
-    const u8* cRrow = a.cR + (size_t)pair * a.strideR + (size_t)y * a.pR + (a.maxD - a.minD - lic * DPLn - (DPLn - 1));
-    u8* Srow = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)y * W * (S4B ? DP : 2 * DP) + lic * 16;
-    const size_t recRow = (size_t)pair * a.strideRec + (size_t)y * W;
+    // addresses as a wave-uniform 64-bit base (the band's lowest image row of this pair) plus 32-bit lane offsets: a band
+    // spans SLOTS rows, so the offsets stay far below 4 GB whatever the image size, and no 64-bit arithmetic or pointer
+    // pair per lane is needed in the loop
+    const int vFirst = band * SLOTS - ra.vofs, vLastC = min(max(vFirst + SLOTS - 1, 0), H - 1), vFirstC = min(max(vFirst, 0), H - 1);
+    const int yLo = UP ? H - 1 - vLastC : vFirstC;
+    const u32 dy = (u32)(y - yLo);
+    const u8* const cLbase = a.cL + (size_t)pair * a.strideL + (size_t)yLo * a.pL;
+    const u8* const cRbase = a.cR + (size_t)pair * a.strideR + (size_t)yLo * a.pR - DP;    // (biased so that the lane offsets below are never negative)
+    constexpr u32 SB = S4B ? DP : 2 * DP;                                   // bytes of a pixel in the S volume
+    u8* const Sbase = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)yLo * W * SB;
+    uint2* const recBase = a.rec + (size_t)pair * a.strideRec + (size_t)yLo * W;
+    const u32 cLoff = dy * (u32)a.pL;
+    const u32 cRoff = dy * (u32)a.pR + (u32)(DP + a.maxD - a.minD - lic * DPLn - (DPLn - 1));
+    const u32 Soff = dy * (u32)W * SB + (u32)lic * 16;
+    const u32 recOff = dy * (u32)W;
     u32 tail[NRT];
     make_tail_n<NRT>(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
@@ -242,19 +259,19 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
     auto fetch = [&](int t) {          // unconditional: out-of-range steps ask for the nearest pixel of the row again
         const int u = min(max(t - 2 * j, 0), W - 1);
         xf = UP ? W - 1 - u : u;
-        clw = *reinterpret_cast<const u32*>(cLrow + (xf & ~3));
-        __builtin_memcpy(rbw, cRrow + xf, 2 * NRT);
+        clw = *reinterpret_cast<const u32*>(cLbase + (cLoff + (u32)(xf & ~3)));
+        __builtin_memcpy(rbw, cRbase + (cRoff + (u32)xf), 2 * NRT);
         if (SECOND) {
             if (S4B) {
 #pragma unroll
                 for (int q = 0; q < PL; q++) {
-                    const uint4 v4 = load16_stream(Srow + (size_t)xf * DP + q * LPC * 16);
+                    const uint4 v4 = load16_stream(Sbase + (Soff + (u32)xf * DP + q * LPC * 16));
                     sbw[4 * q] = v4.x; sbw[4 * q + 1] = v4.y; sbw[4 * q + 2] = v4.z; sbw[4 * q + 3] = v4.w;
                 }
             } else {
 #pragma unroll
                 for (int q = 0; q < NRT / 4; q++) {
-                    const uint4 v4 = load16_stream(Srow + (size_t)xf * 2 * DP + q * LPC * 16);
+                    const uint4 v4 = load16_stream(Sbase + (Soff + (u32)xf * 2 * DP + q * LPC * 16));
                     Sn[4 * q] = v4.x; Sn[4 * q + 1] = v4.y; Sn[4 * q + 2] = v4.z; Sn[4 * q + 3] = v4.w;
                 }
             }
@@ -347,14 +364,14 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                     pack_n<NRT>(Sacc, sw4);
 #pragma unroll
                     for (int q = 0; q < PL; q++)
-                        store16_stream(Srow + (size_t)x * DP + q * LPC * 16, make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
+                        store16_stream(Sbase + (Soff + (u32)x * DP + q * LPC * 16), make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
                 } else {
 #pragma unroll
                     for (int q = 0; q < NRT / 4; q++)
-                        store16_stream(Srow + (size_t)x * 2 * DP + q * LPC * 16, make_uint4(Sacc[4 * q], Sacc[4 * q + 1], Sacc[4 * q + 2], Sacc[4 * q + 3]));
+                        store16_stream(Sbase + (Soff + (u32)x * 2 * DP + q * LPC * 16), make_uint4(Sacc[4 * q], Sacc[4 * q + 1], Sacc[4 * q + 2], Sacc[4 * q + 3]));
                 }
             } else if (FUSE) {
-                wta_n<TAIL, LPC, NRT>(a, Sacc, tail, lic, &srow[j][0], exclMask, recRow + x);
+                wta_n<TAIL, LPC, NRT>(a, Sacc, tail, lic, &srow[j][0], exclMask, recBase + (recOff + (u32)x));
             } else {
                 // volume export: the full sum in natural disparity order, in place of the four-path sum
                 u32 nat[NRT];
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(NT + 64, ((LPC == 16 && NRT == 16) || S16) ? 2 : 4)
                     nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
                     nat[g + NRT / 2] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
                 }
-                uint4* dst = reinterpret_cast<uint4*>(Srow - lic * 16 + (size_t)x * 2 * DP + lic * DPLn * 2);
+                uint4* dst = reinterpret_cast<uint4*>(Sbase + (Soff - (u32)lic * 16 + (u32)x * 2 * DP + (u32)lic * DPLn * 2));
 #pragma unroll
                 for (int q = 0; q < NRT / 4; q++) dst[q] = make_uint4(nat[4 * q], nat[4 * q + 1], nat[4 * q + 2], nat[4 * q + 3]);
             }

@@ -186,7 +186,7 @@ __device__ __forceinline__ void init_excl_mask_n(u32 (*exclMask)[NRT])
 // the record.  Costs must stay below 65536 / (2 NRT).
 template <bool TAIL, int LPC, int NRT>
 __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT], const u32 (&tail)[NRT], int lic, u32* srow,
-                                      const u32 (*exclMask)[NRT], size_t recIndex)
+                                      const u32 (*exclMask)[NRT], uint2* recOut)
 {
     constexpr int DPLn = 2 * NRT, SH = NRT == 8 ? 4 : 5;
     // keys (S * DPL + local index) as packed pairs; while every key stays below 0x7C00 (a.smallS) their minimum is a
@@ -239,21 +239,24 @@ __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT],
     const int mex = (int)row_min16<LPC>(min(smin & 0xFFFFu, smin >> 16));
     // uniqueness: some S(d) with |d - best| > 1 satisfies (S - bias)*(100 - u) < (minS - bias)*100
     const bool notUnique = mex < (int)OUT1 && __mul24(mex - a.bias, 100 - a.uniq) < __mul24(minS - a.bias, 100);
+    // the neighbours of the minimum for the parabola: the pixel's sums go to its LDS row in natural disparity order (16-bit
+    // element d of the row is S(d)), so that the two look-ups are plain 16-bit reads at 2 (best -+ 1), clamped to the range
+    u32 nat[NRT];
+#pragma unroll
+    for (int g = 0; g < NRT / 2; g++) {
+        nat[g] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x05040100u);
+        nat[g + NRT / 2] = __builtin_amdgcn_perm(Sacc[2 * g + 1], Sacc[2 * g], 0x07060302u);
+    }
 #pragma unroll
     for (int q = 0; q < NRT; q += 4)
-        *reinterpret_cast<uint4*>(&srow[(q / 4) * LPC * 4 + lic * 4]) = make_uint4(Sacc[q], Sacc[q + 1], Sacc[q + 2], Sacc[q + 3]);
-    auto s_at = [&](int d) -> u32 {
-        d = min(max(d, 0), LPC * DPLn - 1);
-        const int l = d / DPLn, e = d % DPLn;
-        const int reg = e % NRT, half = e / NRT;
-        return (srow[(reg / 4) * LPC * 4 + l * 4 + (reg & 3)] >> (16 * half)) & 0xFFFFu;
-    };
-    const u32 sm = s_at(best - 1), spl = s_at(best + 1);
+        *reinterpret_cast<uint4*>(&srow[lic * NRT + q]) = make_uint4(nat[q], nat[q + 1], nat[q + 2], nat[q + 3]);
+    const unsigned short* s16row = reinterpret_cast<const unsigned short*>(srow);
+    const u32 sm = s16row[max(best - 1, 0)], spl = s16row[min(best + 1, LPC * DPLn - 1)];
     if (lic == 0) {
         uint2 rec;
         rec.x = (u32)minS | ((u32)best << 16) | (notUnique ? 0x80000000u : 0u);
         rec.y = sm | (spl << 16);
-        a.rec[recIndex] = rec;
+        *recOut = rec;
     }
 }
 
