@@ -25,14 +25,18 @@
 // the consumer side, parked in LDS one step ahead); every wait is bounded and reports through a sticky error word.
 #include "sgm_lanes_n.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
 // Waves per SIMD the register allocation aims at.  A workgroup is five waves on four SIMDs, so 5 waves per SIMD are four
 // workgroups per CU and 4 are three.  The kernels of the headline geometry (16 lanes x 16 disparities, byte sums, no masked
 // disparities) fit 96 registers without spilling; the others keep the larger budget.
-constexpr int sgm3_waves_per_simd(int lpc, int nrt, bool tail, bool s4b, bool s16)
-{ return (lpc == 16 && nrt == 16) || s16 ? 2 : (lpc == 16 && nrt == 8 && !tail && s4b ? 5 : 4); }
+#ifndef SGM3_WPS0
+#define SGM3_WPS0 5
+#endif
+constexpr int sgm3_waves_per_simd(int lpc, int nrt, bool tail, bool s4b, bool s16, int role)
+{ return (lpc == 16 && nrt == 16) || s16 ? 2 : (lpc == 16 && nrt == 8 && !tail && s4b ? (role == 0 ? SGM3_WPS0 : 5) : 4); }
 
 struct RowArgs {
     Sgm2Args a;
@@ -63,7 +67,7 @@ struct RowArgs {
 // 255) -- twice the LDS and hand-off bytes, no pack / unpack.
 // FOUR: the 4-path mode (horizontal + vertical paths only): the two diagonal steps are left out.
 template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
-__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16)) void sgm3_rows_kernel(RowArgs ra)
+__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16, ROLE)) void sgm3_rows_kernel(RowArgs ra)
 {
     constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1 || ROLE == 3, HONLY = ROLE == 3;
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, NW = NRT / 2;
@@ -73,8 +77,9 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
     constexpr int DPB = SW * 4;                   // bytes of one path state per pixel
     static_assert(!(S16 && S4B), "16-bit path states never have byte sums");
     const Sgm2Args& a = ra.a;
-    __shared__ u32 st[2][SLOTS][3][SW];     // [step parity][slot][v, \, /][packed bytes of the pixel]
-    __shared__ u32 hin[2][3][SW];           // the band above's states for slot 0, same parity rule
+    // [step parity][row 0: the band above's states for slot 0, parked by the communication wave; row j + 1: slot j][v, \, /][packed bytes of the pixel]
+    // Slot j reads row j and writes row j + 1, so every slot addresses the row above with the same constant strides.
+    __shared__ u32 st[2][SLOTS + 1][3][SW];
     __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * NRT : 1];
     __shared__ u32 exclMask[FUSE ? DPLn + 3 : 1][NRT];
     __shared__ int s_ticket;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
             }
         };
         auto park = [&](int i, const u32 (&w)[SWN]) {      // hand the fetched states of step i to slot 0
-            if (wants(i)) lds_put(&hin[(i + 1) & 1][which][lic * 4], w);
+            if (wants(i)) lds_put(&st[(i + 1) & 1][0][which][lic * 4], w);
         };
         auto send = [&](int t) {                           // step t has been computed: the last slot's states are in st[t & 1]
             const int u = t - 2 * (SLOTS - 1);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
                 const u32 dst = hand_slot(band, u, which);
 #pragma unroll
                 for (int q = 0; q < PLS; q++)
-                    hand_store16(rsrc, dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS - 1][which][q * PW + lic * 4]));
+                    hand_store16(rsrc, dst + q * LPC * 16, *reinterpret_cast<const uint4*>(&st[t & 1][SLOTS][which][q * PW + lic * 4]));
             }
         };
         auto announce = [&](int t) {                       // the states of steps up to t are in memory
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
     };
     // where this slot reads the row above's states: slot j-1's LDS entry, or (slot 0) what the communication wave parked;
     // both alternate with the parity of t + 1
-    const u32* aboveBase = j > 0 ? &st[0][j - 1][0][lic * 4] : &hin[0][0][lic * 4];
-    const int aboveStride = j > 0 ? SLOTS * 3 * SW : 3 * SW;
+    const u32* const aboveBase = &st[0][j][0][lic * 4];
+    constexpr int PARSTRIDE = (SLOTS + 1) * 3 * SW;      // dwords between the two parity entries
 
     u32 Nh[NRT];                       // the path that runs along the row
     EdgeRegs edge = {INF2, INF2};      // targets of the cross-lane shifts: their row-edge lanes stay "infinite"
@@ -285,13 +290,14 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
     for (int q = 0; q < SWN; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; }
     if (!HONLY) __syncthreads();       // the communication wave has parked pixel 0 and pixel 1 of the row above
     if (!HONLY && j == 0) {                      // slot 0 has no step "-1": it takes pixel 0's states here
-        lds_get(&hin[0][0][lic * 4], V0);
-        lds_get(&hin[0][1][lic * 4], DB);
+        lds_get(&st[0][0][0][lic * 4], V0);
+        lds_get(&st[0][0][1][lic * 4], DB);
     }
     if (!HONLY) __syncthreads();
     // one step: Vuse was read in the previous step, D two steps ago; Vfill / D receive what the row above published in
     // the previous step (D only after its old contents have been consumed)
-    auto step = [&](int t, u32 (&Vuse)[SWN], u32 (&Vfill)[SWN], u32 (&D)[SWN]) {
+    auto step = [&](int t, auto parc, u32 (&Vuse)[SWN], u32 (&Vfill)[SWN], u32 (&D)[SWN]) {
+        constexpr int PAR = decltype(parc)::value;        // t % 2, known at compile time: LDS addresses are base + immediate
         const int u = t - 2 * j;
         const bool active = rowOk && u >= 0 && u < W;
         const int x = xf;
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
             }
         }
         fetch(t + 1);
-        const u32* above = aboveBase + ((t + 1) & 1) * aboveStride;
+        const u32* above = aboveBase + (PAR ^ 1) * PARSTRIDE;
+        u32* const own = const_cast<u32*>(aboveBase) + 3 * SW + PAR * PARSTRIDE;
         u32 curA[SWN];
         if constexpr (!HONLY) {
             lds_get(above, Vfill);
@@ -342,21 +349,21 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
                 path_step(N);
 #pragma unroll
                 for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                lds_put(&st[t & 1][j][2][lic * 4], ow);
+                lds_put(own + 2 * SW, ow);
             }
             if constexpr (!HONLY) {
                 from_bytes(Vuse, N);
                 path_step(N);
 #pragma unroll
                 for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                lds_put(&st[t & 1][j][0][lic * 4], ow);
+                lds_put(own, ow);
             }
             if constexpr (!four && !HONLY) {
                 from_bytes(D, N);
                 path_step(N);
 #pragma unroll
                 for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
-                lds_put(&st[t & 1][j][1][lic * 4], ow);
+                lds_put(own + SW, ow);
             }
             if (!SECOND) {
                 if constexpr (S4B) {
@@ -390,12 +397,13 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
             __syncthreads();   // st[t & 1] complete before the next step reads it
         }
     };
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
     int t = 0;
     for (; t + 2 <= T; t += 2) {
-        step(t, V0, V1, DA);
-        step(t + 1, V1, V0, DB);
+        step(t, P0{}, V0, V1, DA);
+        step(t + 1, P1{}, V1, V0, DB);
     }
-    if (t < T) step(t, V0, V1, DA);
+    if (t < T) step(t, P0{}, V0, V1, DA);
 }
 
 template <int LPC, int NRT, int NT, bool BOTH, bool FOUR = false>
