@@ -30,13 +30,13 @@
 namespace {
 
 // Waves per SIMD the register allocation aims at.  A workgroup is five waves on four SIMDs, so 5 waves per SIMD are four
-// workgroups per CU and 4 are three.  The kernels of the headline geometry (16 lanes x 16 disparities, byte sums, no masked
-// disparities) fit 96 registers without spilling; the others keep the larger budget.
+// workgroups per CU and 4 are three.  The kernels with 16 disparities per lane, byte sums and no masked disparities (the
+// headline geometry among them) fit 96 registers without spilling; the others keep the larger budget.
 #ifndef SGM3_WPS0
 #define SGM3_WPS0 5
 #endif
 constexpr int sgm3_waves_per_simd(int lpc, int nrt, bool tail, bool s4b, bool s16, int role)
-{ return (lpc == 16 && nrt == 16) || s16 ? 2 : (lpc == 16 && nrt == 8 && !tail && s4b ? (role == 0 ? SGM3_WPS0 : 5) : 4); }
+{ return (lpc == 16 && nrt == 16) || s16 ? 2 : (nrt == 8 && !tail && s4b ? (role == 0 ? SGM3_WPS0 : 5) : 4); }
 
 struct RowArgs {
     Sgm2Args a;
