@@ -942,6 +942,9 @@ size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt, bool s16);
 size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt);
 int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                    int naturalOut, bool s4b, bool s16);
+bool md_sgm3_meet_supported(const Sgm2Args& a, int lpc, int dpl, bool s4b, bool s16);
+int md_sgm3_meet(hipStream_t s, const Sgm2Args& a, u8* handDown, u8* handUp, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
+                 int firstDown, int firstUp);
 int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                   bool s4b, bool up, int role, int band0, int nbands, bool s16, int ticket);
 int md_sgm3_ring();
@@ -1186,6 +1189,10 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             md_sgm3_band_range(pl.H, l.lpc, nt, false, 0, r0, &kbd, &ked);        // down over the upper half: bands [0, ked)
             md_sgm3_band_range(pl.H, l.lpc, nt, true, r0, pl.H, &kbu, &keu);      // up over the lower half:   bands [0, keu)
             u8* handDown = extra; u8* handUp = extra + l.bndBytes / 2;
+            if (md_tune(MDISP_TUNE_SGM_ONE_LAUNCH) != 0 && md_sgm3_meet_supported(a, l.lpc, l.dpl, s4b, !l.u8m)) {
+                // both directions and both roles in one launch: the GPU fills and drains once per call, not once per phase
+                MD_TRY(md_sgm3_meet(s, a, handDown, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, ked, keu));
+            } else {
             hipStream_t s2 = aux->aux;
             MD_HIP(hipEventRecord(aux->ev[0], s)); MD_HIP(hipStreamWaitEvent(s2, aux->ev[0], 0));
             MD_TRY(md_sgm3_sweep(s, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 0, 0, ked, !l.u8m, 0));
@@ -1195,6 +1202,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             MD_TRY(md_sgm3_sweep(s, a, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, true, 1, keu, nb - keu, !l.u8m, 2));
             MD_TRY(md_sgm3_sweep(s2, a, handDown, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, s4b, false, 1, ked, nb - ked, !l.u8m, 3));
             MD_HIP(hipEventRecord(aux->ev[0], s2)); MD_HIP(hipStreamWaitEvent(s, aux->ev[0], 0));
+            }
         } else {
             MD_TRY(md_sgm3_sweeps(s, a, extra, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, naturalOut, s4b, !l.u8m));
         }

@@ -52,6 +52,10 @@ struct RowArgs {
     int ticket;             // which of the ticket words in sync[0..15] this launch counts on
     int slack;              // pixels a band stays behind its predecessor beyond the two it needs
     int vofs;               // logical rows of band 0 that lie before the image (so that band edges fall on the same image rows in both directions)
+    // the one-launch schedule (both directions, both roles; sgm3_meet_kernel): the mirrored sweep's ring and padding, the
+    // bands each direction sweeps first, and one word per direction, pair and band that is set when the band's four-path
+    // sums are in memory
+    u8* handUp; int vofsUp; int firstDown, firstUp; int* done;
 };
 
 // LPC lanes share a pixel, each with NRT packed registers (2 NRT disparities); NT compute lanes per workgroup.
@@ -66,8 +70,14 @@ struct RowArgs {
 // S16: the three states that leave the registers travel as 16-bit values (path values that do not fit a byte: 8 + P2 >
 // 255) -- twice the LDS and hand-off bytes, no pack / unpack.
 // FOUR: the 4-path mode (horizontal + vertical paths only): the two diagonal steps are left out.
-template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
-__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16, ROLE)) void sgm3_rows_kernel(RowArgs ra)
+// COH: the four-path sums are written by one workgroup and read by another of the SAME launch (one-launch schedule), so
+// they travel with write-through stores and cache-bypassing loads like the hand-off rows, and a first-sweep band marks
+// itself done when all its stores have completed.
+constexpr int sgm3_state_dwords(int lpc, int nrt, bool s16) { return (s16 ? nrt : nrt / 2) * lpc; }
+template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16, bool FOUR, bool COH>
+__device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band, const int pair,
+                                               u32 (*st)[NT / LPC + 1][3][sgm3_state_dwords(LPC, NRT, S16)], u32 (*srow)[LPC * NRT],
+                                               const u32 (*exclMask)[NRT])
 {
     constexpr bool SECOND = ROLE != 0, FUSE = ROLE == 1 || ROLE == 3, HONLY = ROLE == 3;
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, DP = LPC * DPLn, PL = NRT / 8, PW = LPC * 4, NW = NRT / 2;
@@ -76,22 +86,18 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
     constexpr int SW = PLS * PW;                  // dwords of one path state per pixel
     constexpr int DPB = SW * 4;                   // bytes of one path state per pixel
     static_assert(!(S16 && S4B), "16-bit path states never have byte sums");
+    static_assert(SW == sgm3_state_dwords(LPC, NRT, S16), "state size");
+    static_assert(!COH || (S4B && (ROLE == 0 || ROLE == 1)), "one-launch schedule: byte sums, first and second sweep only");
     const Sgm2Args& a = ra.a;
-    // [step parity][row 0: the band above's states for slot 0, parked by the communication wave; row j + 1: slot j][v, \, /][packed bytes of the pixel]
-    // Slot j reads row j and writes row j + 1, so every slot addresses the row above with the same constant strides.
-    __shared__ u32 st[2][SLOTS + 1][3][SW];
-    __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * NRT : 1];
-    __shared__ u32 exclMask[FUSE ? DPLn + 3 : 1][NRT];
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
-    if (FUSE) init_excl_mask_n<NRT>(exclMask);
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);      // wave-uniform: pair, band and everything derived from them stay in scalar registers
-    // tickets: group after group of pairs; inside a group band after band (dependency order), pair after pair
-    const int perGroup = ra.group * ra.nbands, grp = ticket / perGroup, rem = ticket - grp * perGroup;
-    const int gsz = min(ra.group, ra.batch - grp * ra.group);
-    const int ord = rem / gsz, pair = grp * ra.group + (rem - ord * gsz);
-    const int band = ra.band0 + ord;
+    // a first-sweep band of the one-launch schedule ends here: every store of the workgroup has completed, then its word is set
+    auto finish = [&]() {
+        if constexpr (COH && ROLE == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(ra.done + ((size_t)((UP ? ra.batch : 0) + pair) * ra.nb + band), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const int H = a.H, W = a.W;
     const int T = W + 2 * (SLOTS - 1);                    // steps: slot j works on u = t - 2j
     u8* hand = ra.hand + (size_t)pair * ra.strideHand;
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
         send(T - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         announce(T - 1);
+        finish();
         return;
     }
 
@@ -228,6 +235,23 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
     const u32 cRoff = dy * (u32)a.pR + (u32)(DP + a.maxD - a.minD - lic * DPLn - (DPLn - 1));
     const u32 Soff = dy * (u32)W * SB + (u32)lic * 16;
     const u32 recOff = dy * (u32)W;
+    // byte sums: streaming accesses; in the one-launch schedule (COH) write-through stores and loads that bypass the
+    // non-coherent caches, through a descriptor of the pair's volume (the band's first row as the scalar offset)
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS), 0,
+                                                                           (int)(a.strideS * sizeof(u16)), 0x00020000);
+    const u32 sRowBase = (u32)yLo * (u32)W * SB;
+    auto s4_load = [&](u32 off) -> uint4 {
+        if constexpr (COH) {
+            const md_v4u d = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)off, (int)sRowBase, 18);
+            return make_uint4(d.x, d.y, d.z, d.w);
+        } else return load16_stream(Sbase + off);
+    };
+    auto s4_store = [&](u32 off, const uint4& v) {
+        if constexpr (COH) {
+            md_v4u d = {v.x, v.y, v.z, v.w};
+            __builtin_amdgcn_raw_buffer_store_b128(d, srsrc, (int)off, (int)sRowBase, 18);
+        } else store16_stream(Sbase + off, v);
+    };
     u32 tail[NRT];
     make_tail_n<NRT>(lic, a.D, tail);
     const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
             if (S4B) {
 #pragma unroll
                 for (int q = 0; q < PL; q++) {
-                    const uint4 v4 = load16_stream(Sbase + (Soff + (u32)xf * DP + q * LPC * 16));
+                    const uint4 v4 = s4_load(Soff + (u32)xf * DP + q * LPC * 16);
                     sbw[4 * q] = v4.x; sbw[4 * q + 1] = v4.y; sbw[4 * q + 2] = v4.z; sbw[4 * q + 3] = v4.w;
                 }
             } else {
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
                     pack_n<NRT>(Sacc, sw4);
 #pragma unroll
                     for (int q = 0; q < PL; q++)
-                        store16_stream(Sbase + (Soff + (u32)x * DP + q * LPC * 16), make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
+                        s4_store(Soff + (u32)x * DP + q * LPC * 16, make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
                 } else {
 #pragma unroll
                     for (int q = 0; q < NRT / 4; q++)
@@ -404,6 +428,82 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
         step(t + 1, P1{}, V1, V0, DB);
     }
     if (t < T) step(t, P0{}, V0, V1, DA);
+    finish();
+}
+
+// One sweep (one direction, one role) over a range of bands: the launch counts tickets on its own word.
+template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
+__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16, ROLE)) void sgm3_rows_kernel(RowArgs ra)
+{
+    constexpr bool FUSE = ROLE == 1 || ROLE == 3;
+    constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, SW = sgm3_state_dwords(LPC, NRT, S16);
+    // [step parity][row 0: the band above's states for slot 0, parked by the communication wave; row j + 1: slot j][v, \, /][packed bytes of the pixel]
+    // Slot j reads row j and writes row j + 1, so every slot addresses the row above with the same constant strides.
+    __shared__ u32 st[2][SLOTS + 1][3][SW];
+    __shared__ u32 srow[FUSE ? SLOTS : 1][FUSE ? LPC * NRT : 1];
+    __shared__ u32 exclMask[FUSE ? DPLn + 3 : 1][NRT];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
+    if (FUSE) init_excl_mask_n<NRT>(exclMask);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);      // wave-uniform: pair, band and everything derived from them stay in scalar registers
+    // tickets: group after group of pairs; inside a group band after band (dependency order), pair after pair
+    const int perGroup = ra.group * ra.nbands, grp = ticket / perGroup, rem = ticket - grp * perGroup;
+    const int gsz = min(ra.group, ra.batch - grp * ra.group);
+    const int ord = rem / gsz, pair = grp * ra.group + (rem - ord * gsz);
+    const int band = ra.band0 + ord;
+    sgm3_rows_body<UP, ROLE, TAIL, S4B, LPC, NRT, NT, S16, FOUR, false>(ra, band, pair, st, reinterpret_cast<u32 (*)[LPC * NRT]>(&srow[0][0]), exclMask);
+}
+
+// The one-launch schedule: both directions and both roles of every pair in ONE launch.  Tickets enumerate, band step after
+// band step, the down sweep's and the up sweep's band of every pair; a direction's first bands store their four-path sums,
+// the others -- past the row where the two sweeps meet -- add the sums the other direction stored there and run the
+// winner-take-all.  A second-sweep band waits for the first-sweep band of the other direction that covers the same image
+// rows (an earlier ticket: it has started), so the GPU fills once and drains once per call instead of once per phase.
+template <bool TAIL, int LPC, int NRT, int NT>
+__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, false, 1)) void sgm3_meet_kernel(RowArgs ra)
+{
+    constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, SW = sgm3_state_dwords(LPC, NRT, false);
+    __shared__ u32 st[2][SLOTS + 1][3][SW];
+    __shared__ u32 srow[SLOTS][LPC * NRT];
+    __shared__ u32 exclMask[DPLn + 3][NRT];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
+    init_excl_mask_n<NRT>(exclMask);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    // inside a band step the direction that sweeps first over more bands comes first: with an odd number of bands the middle
+    // band is that direction's last first-sweep band and the other direction's first second-sweep band
+    const int perStep = 2 * ra.batch, band = ticket / perStep, r = ticket - band * perStep;
+    const bool up = (r >= ra.batch) != (ra.firstUp > ra.firstDown);
+    const int pair = r >= ra.batch ? r - ra.batch : r;
+    // (Both directions must change roles at the same band step: a second-sweep band waits for the other direction's band
+    // nb - 1 - band, which has an earlier ticket only while band > nb - 1 - band.  Where the sweeps meet, that band
+    // started just one band step earlier, so the first second-sweep bands wait for most of a band's duration.)
+    const bool second = band >= (up ? ra.firstUp : ra.firstDown);
+    if (second) {
+        // the other direction's band over the same image rows (band edges coincide in the two directions)
+        if (threadIdx.x == 0) {
+            const int* flag = ra.done + ((size_t)((up ? 0 : ra.batch) + pair) * ra.nb + (ra.nb - 1 - band));
+            unsigned long long t0 = 0;
+            for (int it = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; it++) {
+                if ((it & 63) == 63) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > HANDOFF_TIMEOUT_TICKS) { __hip_atomic_store(ra.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (__hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
+    RowArgs rl = ra;
+    if (up) { rl.hand = ra.handUp; rl.vofs = ra.vofsUp; }
+    if (!up && !second) sgm3_rows_body<false, 0, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
+    else if (up && !second) sgm3_rows_body<true, 0, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
+    else if (up) sgm3_rows_body<true, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
+    else sgm3_rows_body<false, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
 }
 
 template <int LPC, int NRT, int NT, bool BOTH, bool FOUR = false>
@@ -472,7 +572,8 @@ int md_sgm3_ring()
 }
 size_t md_sgm3_hand_bytes(int H, int W, int lpc, int dpl, int nt, bool s16)
 { (void)H; (void)nt; return md_align((size_t)md_sgm3_ring() * md_sgm3_boundary_bytes(W, lpc, dpl, s16), 256); }
-size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 2 * (size_t)batch * (md_sgm3_bands(H, lpc, nt) + 1)) * sizeof(int), 256); }
+// tickets (16 words), progress words of the two directions, "band done" words of the two directions (one-launch schedule)
+size_t md_sgm3_sync_bytes(int H, int batch, int lpc, int nt) { return md_align((16 + 4 * (size_t)batch * (md_sgm3_bands(H, lpc, nt) + 1)) * sizeof(int), 256); }
 
 // Logical bands of one sweep that cover the image rows [r0, r1) (r0 a multiple of the band height, r1 a multiple or H)
 void md_sgm3_band_range(int H, int lpc, int nt, bool up, int r0, int r1, int* kb, int* ke)
@@ -527,4 +628,37 @@ int md_sgm3_sweeps(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand
 {
     MD_TRY(md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, false, 0, 0, -1, s16, -1));
     return md_sgm3_sweep(s, a, hand, strideHand, sync, err, batch, lpc, dpl, nt, s4b, true, naturalOut ? 2 : 1, 0, -1, s16, -1);
+}
+
+// The one-launch schedule (sgm3_meet_kernel): the down sweep starts at the top, the up sweep at the bottom, each stores its
+// four-path sums over its first `firstDown` / `firstUp` bands and continues past the meeting row as the second sweep.
+// 16 lanes x 16 disparities, byte sums, no masked disparities, eight paths; a pair's sum volume must lie below 4 GB
+// (one buffer descriptor).  `sync` must be zero.
+bool md_sgm3_meet_supported(const Sgm2Args& a, int lpc, int dpl, bool s4b, bool s16)
+{
+    return lpc == 16 && dpl == 16 && s4b && !s16 && !a.tail && !a.four && !a.five && a.strideS * sizeof(u16) < ((size_t)1 << 32);
+}
+int md_sgm3_meet(hipStream_t s, const Sgm2Args& a, u8* handDown, u8* handUp, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
+                 int firstDown, int firstUp)
+{
+    MD_REQUIRE(md_sgm3_meet_supported(a, lpc, dpl, true, false) && nt == 256, MDISP_E_UNSUPPORTED, "row bands: the one-launch schedule is not built for this geometry");
+    RowArgs ra;
+    ra.a = a; ra.hand = handDown; ra.handUp = handUp; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
+    const int rows = nt / lpc;
+    ra.nb = md_sgm3_bands(a.H, lpc, nt); ra.batch = batch; ra.band0 = 0; ra.nbands = ra.nb; ra.group = batch;
+    ra.vofs = 0; ra.vofsUp = ra.nb * rows - a.H;
+    ra.ringMask = md_sgm3_ring() - 1;
+    ra.ticket = 0;
+    ra.firstDown = firstDown; ra.firstUp = firstUp;
+    ra.done = sync + 16 + 2 * (size_t)batch * (ra.nb + 1);
+    // a second-sweep band waits for the other direction's band nb - 1 - band: that is an earlier ticket only if both
+    // directions sweep first over (nearly) half of the bands
+    MD_REQUIRE(firstDown + firstUp == ra.nb && 2 * firstDown >= ra.nb - 1 && 2 * firstUp >= ra.nb - 1, MDISP_E_BADARG,
+               "row bands: the two first sweeps must cover the image exactly once and meet in the middle");
+    MD_REQUIRE(strideHand < ((size_t)1 << 32), MDISP_E_RANGE, "row bands: hand-off ring of %zu bytes per pair exceeds 4 GB", strideHand);
+    { const int sl = md_tune(MDISP_TUNE_SGM_BAND_SLACK); ra.slack = sl > 0 ? sl : 0; }
+    const dim3 g((unsigned)(2 * ra.nb) * batch);
+    sgm3_meet_kernel<false, 16, 8, 256><<<g, 256 + 64, 0, s>>>(ra);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
 }

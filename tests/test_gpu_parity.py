@@ -226,6 +226,9 @@ def sgm_schedule(request):
 BATCH_CASES = [
     # B, H, W, pitch, D, minD, P2, tuning
     (9, 70, 150, 150, 256, 0, 32, {}),                          # row bands, several pairs per band level
+    (9, 70, 150, 150, 256, 0, 32, {"SGM_ONE_LAUNCH": 0}),       # both edges at once as two launches per phase instead of one launch
+    (7, 100, 130, 130, 256, 0, 32, {}),                         # one launch, an odd number of bands (the middle band changes roles between the directions)
+    (7, 128, 130, 130, 256, 0, 32, {"SGM_HAND_RING": 2}),       # one launch, an even number of bands, the smallest hand-off ring
     (9, 70, 150, 150, 256, 0, 32, {"SGM_PAIR_GROUP": 4}),       # pairs dispatched in groups, the last group partial
     (5, 45, 300, 300, 512, 0, 32, {}),                          # 32 disparities per lane
     (3, 90, 210, 210, 300, 2, 60, {}),                          # a few pairs at D > 256: sweeps from both image edges, 16-bit sums
@@ -413,6 +416,28 @@ def test_sgm_full_size_frame_bit_exact(api, orc, sgm_schedule):
     valid = got >= 0
     assert valid.mean() > 0.6
     assert np.median(np.abs(got[valid] / 16.0 - gt[valid])) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tuning", [{}, {"SGM_ONE_LAUNCH": 0}])
+def test_sgm_batch_full_size_fills_the_gpu(api, orc, tuning):
+    """A batch of full-size frames that occupies every workgroup slot several times over (the one-launch schedule hands
+    four-path sums between workgroups of one launch, on whatever part of the chip they run): every pair equals the oracle
+    for the first frames and the single-pair call, which another test pins to the oracle, for the rest."""
+    from cameracalibration_amd import _lib
+    B, H, W, D = 20, 1080, 1920, 256
+    par = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+    pairs = [api.synth_pair(0x5EED0101 + 2 * i, H, W, D)[:2] for i in range(B)]
+    _lib.tuning_reset()
+    try:
+        for k, v in tuning.items():
+            _lib.tuning_set(getattr(_lib, "TUNE_" + k), v)
+        got = api.sgbm_compute_batch([a for a, _ in pairs], [b for _, b in pairs], par, chunk=B)
+    finally:
+        _lib.tuning_reset()
+    for i, (a, b) in enumerate(pairs):
+        exp = orc.sgm(a, b, 0, D, 8, 32, 10, 1, 8, 1) if i < 3 else api.sgbm_compute(a, b, par)
+        assert np.array_equal(got[i], exp), "pair %d" % i
 
 
 @pytest.mark.gpu
