@@ -276,8 +276,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_copy": copy_gbs.value or None,
                          "frac_of_measured": achieved / copy_gbs.value if copy_gbs.value else None,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "all launches of one batch call, per pair (census, the two row-band sweeps started from both image edges: "
-                                   "first halves, then second halves + WTA; LR/sub-pixel)" if args.paths == 8 else "all launches of one batch call, per pair",
+                         "kernel": "all launches of one batch call, per pair (census; ONE row-band launch with both sweep directions started from "
+                                   "the two image edges, first halves then second halves + WTA; LR/sub-pixel)" if args.paths == 8 else "all launches of one batch call, per pair",
                          "ms_per_pair": pair_s * 1e3, "ms_aggregation_per_pair": float(np.mean(agg_ms)) / B,
                          "algorithmic_bytes_per_pair": alg_bytes},
         }

@@ -1189,8 +1189,11 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
             md_sgm3_band_range(pl.H, l.lpc, nt, false, 0, r0, &kbd, &ked);        // down over the upper half: bands [0, ked)
             md_sgm3_band_range(pl.H, l.lpc, nt, true, r0, pl.H, &kbu, &keu);      // up over the lower half:   bands [0, keu)
             u8* handDown = extra; u8* handUp = extra + l.bndBytes / 2;
-            if (md_tune(MDISP_TUNE_SGM_ONE_LAUNCH) != 0 && md_sgm3_meet_supported(a, l.lpc, l.dpl, s4b, !l.u8m)) {
-                // both directions and both roles in one launch: the GPU fills and drains once per call, not once per phase
+            // both directions and both roles in one launch: the GPU fills and drains once per call, not once per phase
+            // (64 pairs: 0.797 -> 0.767 ms per pair, 16 pairs: 1.30 -> 1.15).  Very large batches amortise the phase change
+            // anyway and run 1-3 % faster as two launches per phase (128 pairs: 0.720 against 0.730 ms per pair).
+            const int oneLaunch = md_tune(MDISP_TUNE_SGM_ONE_LAUNCH);
+            if ((oneLaunch > 0 || (oneLaunch < 0 && batch <= 96)) && md_sgm3_meet_supported(a, l.lpc, l.dpl, s4b, !l.u8m)) {
                 MD_TRY(md_sgm3_meet(s, a, handDown, handUp, l.bndBytes, sync, errWord, batch, l.lpc, l.dpl, nt, ked, keu));
             } else {
             hipStream_t s2 = aux->aux;

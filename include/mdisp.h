@@ -458,7 +458,7 @@ enum {
     MDISP_TUNE_SGM_PAIR_GROUP = 10,    /* row bands: pairs whose bands are dispatched together (band-major inside a group) */
     MDISP_TUNE_SGM_HAND_RING = 11,     /* row bands: entries of the hand-off ring (2..32, a power of two; default 32) */
     MDISP_TUNE_SGM_MEET_MAX = 12,      /* row bands: largest batch whose two sweeps start from both image edges at once (default: any) */
-    MDISP_TUNE_SGM_ONE_LAUNCH = 13,    /* row bands: 0 = the two sweep directions as two launches per phase; default: both directions and both roles in one launch */
+    MDISP_TUNE_SGM_ONE_LAUNCH = 13,    /* row bands: 0 = the two sweep directions as two launches per phase, 1 = both directions and both roles in one launch; default: one launch up to 96 pairs */
     MDISP_TUNE_COUNT = 14
 };
 int mdisp_tuning_set(int key, int value);

@@ -29,7 +29,7 @@ def main():
         agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVES":
             launches[m.group(1)] += 1
-    batches = max(v for k, v in launches.items() if "shear" in k or "sweep" in k or "stagger" in k or "rows" in k)
+    batches = max(v for k, v in launches.items() if "shear" in k or "sweep" in k or "stagger" in k or "rows" in k or "meet" in k)
     rows, total = [], 0.0
     for k, c in agg.items():
         valu = c["SQ_INSTS_VALU"] / batches / pairs
