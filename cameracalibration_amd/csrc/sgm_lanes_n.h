@@ -186,7 +186,7 @@ __device__ __forceinline__ void init_excl_mask_n(u32 (*exclMask)[NRT])
 // the record.  Costs must stay below 65536 / (2 NRT).
 template <bool TAIL, int LPC, int NRT>
 __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT], const u32 (&tail)[NRT], int lic, u32* srow,
-                                      const u32 (*exclMask)[NRT], uint2* recOut)
+                                      const u32 (*exclMask)[NRT], uint2* recOut, bool store = true)
 {
     constexpr int DPLn = 2 * NRT, SH = NRT == 8 ? 4 : 5;
     // keys (S * DPL + local index) as packed pairs; while every key stays below 0x7C00 (a.smallS) their minimum is a
@@ -252,7 +252,7 @@ __device__ __forceinline__ void wta_n(const Sgm2Args& a, const u32 (&Sacc)[NRT],
         *reinterpret_cast<uint4*>(&srow[lic * NRT + q]) = make_uint4(nat[q], nat[q + 1], nat[q + 2], nat[q + 3]);
     const unsigned short* s16row = reinterpret_cast<const unsigned short*>(srow);
     const u32 sm = s16row[max(best - 1, 0)], spl = s16row[min(best + 1, LPC * DPLn - 1)];
-    if (lic == 0) {
+    if (lic == 0 && store) {
         uint2 rec;
         rec.x = (u32)minS | ((u32)best << 16) | (notUnique ? 0x80000000u : 0u);
         rec.y = sm | (spl << 16);
