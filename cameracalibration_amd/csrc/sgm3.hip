@@ -346,7 +346,7 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
         // one or in a padding row works on garbage that no active slot ever uses: paths that enter the image are started
         // afresh by the border cases below); only the stores are conditional.  Without the branch around the step the row
         // path's registers need no copies where the two branches would meet.
-        constexpr bool ALWAYS = COH;
+        constexpr bool ALWAYS = true;
         if (ALWAYS || active) {
             // paths that start at this pixel (image border): rare, so the per-lane selects sit behind a wave-level test
             const bool firstCol = u == 0, lastCol = u == W - 1;
@@ -398,18 +398,24 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
                 if constexpr (S4B) {
                     u32 sw4[NW];
                     pack_n<NRT>(Sacc, sw4);
+                    if constexpr (COH) {
 #pragma unroll
-                    for (int q = 0; q < PL; q++)
-                        s4_store(ALWAYS && !active ? 0xFFFFFFF0u : Soff + (u32)x * DP + q * LPC * 16,      // (beyond the descriptor's range: dropped)
-                                 make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
-                } else {
+                        for (int q = 0; q < PL; q++)
+                            s4_store(!active ? 0xFFFFFFF0u : Soff + (u32)x * DP + q * LPC * 16,      // (beyond the descriptor's range: dropped)
+                                     make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
+                    } else if (active) {
+#pragma unroll
+                        for (int q = 0; q < PL; q++)
+                            s4_store(Soff + (u32)x * DP + q * LPC * 16, make_uint4(sw4[4 * q], sw4[4 * q + 1], sw4[4 * q + 2], sw4[4 * q + 3]));
+                    }
+                } else if (active) {
 #pragma unroll
                     for (int q = 0; q < NRT / 4; q++)
                         store16_stream(Sbase + (Soff + (u32)x * 2 * DP + q * LPC * 16), make_uint4(Sacc[4 * q], Sacc[4 * q + 1], Sacc[4 * q + 2], Sacc[4 * q + 3]));
                 }
             } else if (FUSE) {
                 wta_n<TAIL, LPC, NRT>(a, Sacc, tail, lic, &srow[j][0], exclMask, recBase + (recOff + (u32)x), active);
-            } else {
+            } else if (active) {
                 // volume export: the full sum in natural disparity order, in place of the four-path sum
                 u32 nat[NRT];
 #pragma unroll
