@@ -78,6 +78,22 @@ def measured_issue_bound():
 def side_path(args):
     """Side measurements of the other device-resident paths (one GPU, one pair per call: what their callers do).  The
     headline line is `--path sgm`; these print the same kind of line so that they can be recorded next to it."""
+    print(json.dumps(measure_side(args)), flush=True)
+
+
+def side_summary():
+    """The side measurements in short form, for the headline line: ms per call of the cv::StereoSGBM replacement (both modes) at
+    the headline frame size and of census + box + WTA at 640x480, D=64 (each a few calls, well under a second)."""
+    out = {}
+    for name, path, hh in (("stereosgbm_1920x1080_D256_mode_sgbm", "stereosgbm", False), ("stereosgbm_1920x1080_D256_mode_hh", "stereosgbm", True),
+                           ("census_box_wta_640x480_D64", "census_box", False)):
+        a = argparse.Namespace(path=path, disp=256, paths=8, hh=hh, steps=10, warmup=3)
+        r = measure_side(a)
+        out[name] = {"ms_per_call": r["ms_per_step"], "Mdisp_per_s": r["value"], "workload": r["config"]["workload"]}
+    return out
+
+
+def measure_side(args):
     import torch
     from cameracalibration_amd import _lib, api
     lib = _lib.load()
@@ -121,13 +137,13 @@ def side_path(args):
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
     per = elapsed / args.steps
-    print(json.dumps({
+    return ({
         "metric": f"Mdisp/s (WxHxD per sec) at {w}x{h}, D={d}", "value": w * h * d / per / 1e6, "unit": "Mdisp/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "s16" if args.path == "stereosgbm" else "u16", "data": "synthetic",
         "config": {"workload": workload, "path": args.path},
         "roofline": {"bound": "hbm", "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / per / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_pair": alg}}), flush=True)
+                     "traffic": None, "algorithmic_bytes_per_pair": alg}})
 
 
 def main():
@@ -289,6 +305,8 @@ def main():
             from oracle import orc
             orc.build()
             out["cpu_baseline"] = cpu_baseline(orc, api)
+        if world == 1 and args.paths == 8 and D == 256 and not args.no_cpu_baseline:
+            out["side_measurements"] = side_summary()      # not part of the timed region: one pair per call, device-resident
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
