@@ -108,35 +108,55 @@ __global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restric
 #define BT_MULTI_MAX_UNITS ((size_t)96 << 20)   // cost-volume elements up to which a group's directions share one launch
 #define BT_SEG 128     // columns per marching segment of bt_cost_hsum_kernel
 #define BT_VBAND 120   // rows per marching band of bt_vsum_kernel
+template <int CN>      // channels at compile time (the plane loop of a pixel cost unrolls); 0: any
 __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict__ p1, const u8* __restrict__ p2, BtGeom g,
                                                            int16_t* __restrict__ out)
 {
-    // [2 * np][W + 2]: left planes, then right planes, every row with its edge pixels repeated once on either side:
-    // the interpolated neighbours (u + u(x-1)) / 2 and (u + u(x+1)) / 2 of an edge pixel are then the pixel itself, as the
-    // library defines them, and every read is unconditional (a read under a per-lane condition is waited for alone)
-    extern __shared__ u8 planeRows[];
-    const int np = 2 * g.cn, W = g.W, WP = W + 2, y = blockIdx.y;
-    for (int i = threadIdx.x; i < np * WP; i += 256) {
-        const int c = i / WP, x = min(max(i - c * WP - 1, 0), W - 1);
-        planeRows[i] = p1[(size_t)c * g.N + (size_t)y * W + x];
-        planeRows[np * WP + i] = p2[(size_t)c * g.N + (size_t)y * W + x];
+    // Per plane and pixel of image row y one dword: the value u, and the minimum u0 and maximum u1 of u and its two
+    // half-way neighbours (u + u(x-1)) / 2, (u + u(x+1)) / 2 -- at the image edge the pixel itself, as the library defines
+    // them.  [2 * np][TS]: left planes, then right planes, for the TS = BT_SEG + 256 + bs columns from `lo` on that this
+    // workgroup's segment and candidates can reach.  A pixel cost is then two table reads per plane (the left one the same
+    // for every lane) and a dozen integer operations, whatever the candidate.
+    extern __shared__ u32 btTable[];
+    const int cn = CN ? CN : g.cn, np = 2 * cn, W = g.W, y = blockIdx.y;
+    const int h = g.bs / 2, W1 = g.W1;
+    const int xa = blockIdx.z * BT_SEG, xb = min(xa + BT_SEG, W1);
+    const int k = blockIdx.x * 256 + threadIdx.x, TS = BT_SEG + 256 + g.bs;
+    int tlo;
+    {
+        const int kHi = min(blockIdx.x * 256 + 255, g.D - 1);
+        const int xl0 = max(xa - h, 0) + g.minX1, xl1 = min(xb - 1 + h, W1 - 1) + g.minX1;      // left columns of the segment's windows
+        const int lo = max(min(xl0, xl0 - (g.minD + kHi)), 0), hi = min(max(xl1, xl1 - (g.minD + (int)blockIdx.x * 256)), W - 1);
+        const int n = hi - lo + 1;
+        tlo = lo;
+        for (int i = threadIdx.x; i < 2 * np * n; i += 256) {
+            const int c = i / n, x = lo + i - c * n;
+            const u8* row = (c < np ? p1 + (size_t)c * g.N : p2 + (size_t)(c - np) * g.N) + (size_t)y * W;
+            const int u = row[x], ul = (u + row[max(x - 1, 0)]) / 2, ur = (u + row[min(x + 1, W - 1)]) / 2;
+            btTable[c * TS + x - lo] = (u32)u | ((u32)min(min(ul, ur), u) << 8) | ((u32)max(max(ul, ur), u) << 16);
+        }
     }
     __syncthreads();
-    const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= g.D) return;
-    const int h = g.bs / 2, W1 = g.W1;
     auto pix = [&](int x1) -> int {
         const int x = x1 + g.minX1, x2 = x - (g.minD + k);
         int cost = 0;
-        for (int c = 0; c < np; c++) cost += bt_one_padded(planeRows + c * WP + 1, planeRows + (np + c) * WP + 1, x, x2) >> (c < g.cn ? 0 : 2);
+#pragma unroll
+        for (int c = 0; c < np; c++) {
+            const u32 l = btTable[c * TS + x - tlo], r = btTable[(np + c) * TS + x2 - tlo];
+            const int u = l & 0xFF, u0 = (l >> 8) & 0xFF, u1 = (l >> 16) & 0xFF;
+            const int v = r & 0xFF, v0 = (r >> 8) & 0xFF, v1 = (r >> 16) & 0xFF;
+            const int c0 = max(max(0, u - v1), v0 - u);
+            const int c1 = max(max(0, v - u1), u0 - v);
+            cost += min(c0, c1) >> (c < cn ? 0 : 2);
+        }
         return cost;
     };
     // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window.
     // Every pixel cost is evaluated once: a lane keeps the costs of the window's columns in its own ring of bs + 1
     // slots in LDS ([slot][lane], conflict-free), so the column that leaves the window is read back, not recomputed.
-    int16_t* ring = reinterpret_cast<int16_t*>(planeRows + ((2 * np * WP + 3) & ~3)) + threadIdx.x;
+    int16_t* ring = reinterpret_cast<int16_t*>(btTable + 2 * np * TS) + threadIdx.x;
     const int R = g.bs + 1;
-    const int xa = blockIdx.z * BT_SEG, xb = min(xa + BT_SEG, W1);
     int slotLeave = (xa - h) % R;
     if (slotLeave < 0) slotLeave += R;
     int slotEnter = slotLeave;
@@ -652,9 +672,12 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
     // plane rows + the per-lane ring of pixel costs (bs + 1 slots of 256 int16)
-    const size_t rowLds = (((size_t)4 * cn * (W + 2) + 3) & ~(size_t)3) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
+    const size_t rowLds = (size_t)4 * cn * (BT_SEG + 256 + g.bs) * sizeof(u32) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
     if (rowLds <= 60 * 1024) {
-        bt_cost_hsum_kernel<<<dim3((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG), 256, rowLds, s>>>(pl1, pl2, g, v1);
+        const dim3 gh((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG);
+        if (cn == 1) bt_cost_hsum_kernel<1><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
+        else if (cn == 3) bt_cost_hsum_kernel<3><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
+        else bt_cost_hsum_kernel<0><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
         bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D / 4), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
     } else {
         bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
