@@ -405,15 +405,17 @@ struct SelArgs {
 // One workgroup per image row: first-minimum WTA, uniqueness, disp2 election (minimum S, ties to
 // the larger x: the library walks right to left with a strict '>'), x16 parabola, then the
 // disp12MaxDiff check.  Columns left of minX1 stay invalid.
+#define BT_SEL_THREADS 1024      // sixteen waves per image row: the loop over a wave's pixels is a serial chain (wave-wide minimum, lane reads, LDS atomic)
 template <int ND>
-__global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
+__global__ __launch_bounds__(BT_SEL_THREADS) void bt_select_kernel(SelArgs a)
 {
+    constexpr int NWAVES = BT_SEL_THREADS / 64;
     extern __shared__ u32 lds[];
     u32* key = lds;                                            // [W] (S + 32768) << 16 | (0xFFFF - x)
     int16_t* d1 = reinterpret_cast<int16_t*>(lds + a.W);       // [W]
     const int y = blockIdx.x, W = a.W, D = a.D;
     const int INVALID = (a.minD - 1) * 16;
-    for (int i = threadIdx.x; i < W; i += 256) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
+    for (int i = threadIdx.x; i < W; i += BT_SEL_THREADS) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // lane l holds the ND consecutive sums l*ND .. l*ND+ND-1 of a pixel (one vector load); D is a multiple of 16 >= ND
@@ -423,11 +425,11 @@ __global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
     V cur;
     __builtin_memset(&cur, 0, sizeof(V));
     if (mine && wv < a.W1) cur = *reinterpret_cast<const V*>(a.S + ((size_t)y * a.W1 + wv) * D + k0);
-    for (int x1 = wv; x1 < a.W1; x1 += 4) {
+    for (int x1 = wv; x1 < a.W1; x1 += NWAVES) {
         const int16_t* sp = a.S + ((size_t)y * a.W1 + x1) * D;
         int16_t sv[ND];
         __builtin_memcpy(sv, &cur, sizeof(V));
-        if (mine && x1 + 4 < a.W1) cur = *reinterpret_cast<const V*>(sp + (size_t)4 * D + k0);      // next pixel in flight
+        if (mine && x1 + NWAVES < a.W1) cur = *reinterpret_cast<const V*>(sp + (size_t)NWAVES * D + k0);      // next pixel in flight
         u32 best = 0xFFFFFFFFu;
         if (mine) {
 #pragma unroll
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void bt_select_kernel(SelArgs a)
         }
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
+    for (int x = threadIdx.x; x < W; x += BT_SEL_THREADS) {
         int v = d1[x];
         if (v != INVALID && x >= a.minX1) {
             auto inconsistent = [&](int xx, int dd) -> bool {
@@ -662,7 +664,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
         // (the median and speckle stages keep it constant)
         SelArgs sa{};
         sa.S = nullptr; sa.H = H; sa.W = W; sa.W1 = 0; sa.D = g.D; sa.minD = g.minD; sa.minX1 = W; sa.uniq = 0; sa.maxDiff = 1; sa.disp = dDisp;
-        bt_select_kernel<1><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+        bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
         MD_HIP(hipGetLastError());
         if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, dDisp, N * 2, hipMemcpyDeviceToDevice, s));
         return MDISP_OK;
@@ -748,10 +750,10 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     sa.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
     sa.maxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     sa.disp = raw;
-    if (nd == 1) bt_select_kernel<1><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
-    else if (nd == 2) bt_select_kernel<2><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
-    else if (nd == 4) bt_select_kernel<4><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
-    else bt_select_kernel<8><<<H, 256, (size_t)W * 6 + 16, s>>>(sa);
+    if (nd == 1) bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
+    else if (nd == 2) bt_select_kernel<2><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
+    else if (nd == 4) bt_select_kernel<4><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
+    else bt_select_kernel<8><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
     MD_HIP(hipGetLastError());
     if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, raw, N * 2, hipMemcpyDeviceToDevice, s));
     const bool speckle = p->speckleWindowSize > 0;
