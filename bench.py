@@ -257,6 +257,20 @@ def main():
     torch.cuda.synchronize()
     pair_s = float(np.mean(call_ms)) / 1e3 / B      # device time per pair, whole pipeline
 
+    # the batch just timed against another schedule of the same library: the first and the last pair through the single-pair
+    # call (whose full-size output the test suite pins to the CPU oracle bit for bit)
+    verified = None
+    if rank == 0:
+        single = torch.empty((H, W), dtype=torch.int16, device="cuda")
+        same = True
+        for i in (0, B - 1):
+            _lib.check(lib.mdisp_sgbm_dev(ctx.handle, lefts[i].data_ptr(), rights[i].data_ptr(), H, W, W, C.byref(params), single.data_ptr(), None, 0))
+            ctx.synchronize()
+            same = same and bool(torch.equal(single, disp[i]))
+        verified = "pairs 0 and %d of the timed batch equal the single-pair call bit for bit" % (B - 1) if same else "MISMATCH against the single-pair call"
+        if not same:
+            raise SystemExit("bench.py: the batch result differs from the single-pair call")
+
     # what HBM delivers on this device: streaming copy of 2 GiB between two allocations of their own (read + written bytes)
     copy_gbs = C.c_float(0)
     del ws
@@ -288,6 +302,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"1920x1080 D={D} census-Hamming cost + SGM {args.paths}-path + WTA/uniqueness + x16 subpixel + LR check",
                        "pairs_per_gpu_per_step": args.pairs, "P1": P1, "P2": P2, "parallelism": f"pair-sharded x{world}"},
+            "verified": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured_stream_copy": copy_gbs.value or None,
                          "frac_of_measured": achieved / copy_gbs.value if copy_gbs.value else None,
