@@ -23,6 +23,11 @@
 // b before band b+1), so a workgroup only waits for one that started earlier; an extra "communication" wave per
 // workgroup does the exchange (agent-scope write-through stores, drain, then the progress word; agent-scope loads on
 // the consumer side, parked in LDS one step ahead); every wait is bounded and reports through a sticky error word.
+//
+// Launches: one kernel per sweep direction and role over a range of bands (sgm3_rows_kernel: large batches, the row-sharded
+// entry point, geometries other than 16 lanes x 16 disparities), or -- batches of up to 96 pairs of the headline
+// geometry -- ONE kernel for both directions and both roles (sgm3_meet_kernel), in which the four-path sums pass from a
+// first-sweep workgroup to a second-sweep workgroup of the same launch.  Both share the sweep body sgm3_rows_body.
 #include "sgm_lanes_n.h"
 #include <algorithm>
 #include <type_traits>
