@@ -282,6 +282,44 @@ def test_sgm_batch_variants(api, orc, B, H, W, pitch, D, minD, P2, tuning):
         _lib.tuning_reset()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tuning", [{}, {"SGM_ONE_LAUNCH": 0}, {"SGM_MEET_MAX": 0}, {"SGM_PIPELINE": 1}])
+def test_sgm_batch_ignores_what_the_workspace_held(api, orc, tuning):
+    """A caller's workspace arrives with whatever the previous user left in it: the maps must not depend on it (every word
+    the kernels read -- tickets, progress and done words, hand-off rows, sums, records -- is written or cleared by the call)."""
+    import ctypes as C
+    import torch
+    from cameracalibration_amd import _lib
+    lib = _lib.load()
+    _lib.tuning_reset()
+    try:
+        for k, v in tuning.items():
+            _lib.tuning_set(getattr(_lib, "TUNE_" + k), v)
+        B, H, W, D = 12, 150, 260, 256
+        params = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+        Ls, Rs = zip(*[rand_pair(3000 + 5 * i, H, W, 200) for i in range(B)])
+        dl, dr = torch.from_numpy(np.stack(Ls)).cuda(), torch.from_numpy(np.stack(Rs)).cuda()
+        nbytes = lib.mdisp_sgbm_batch_workspace_bytes(H, W, B, C.byref(params))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        ctx = _lib.Context()
+        maps = []
+        for fill in (0, 255, None):
+            if fill is None:
+                ws.random_(0, 255)
+            else:
+                ws.fill_(fill)
+            out = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
+            torch.cuda.synchronize()                           # the context runs on a stream of its own: the fill has to be complete
+            _lib.check(lib.mdisp_sgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), B, H * W, H, W, W, C.byref(params),
+                                                out.data_ptr(), ws.data_ptr(), nbytes))
+            ctx.synchronize()
+            maps.append(out.cpu().numpy())
+        assert np.array_equal(maps[0][0], orc.sgm(Ls[0], Rs[0], 0, D, 8, 32, 10, 1, 8, 1))
+        assert np.array_equal(maps[0], maps[1]) and np.array_equal(maps[0], maps[2])
+    finally:
+        _lib.tuning_reset()
+
+
 @pytest.mark.parametrize("B,H,W,pitch,D,minD,P2", BATCH5_CASES)
 def test_sgm_five_path_batches(api, orc, B, H, W, pitch, D, minD, P2):
     """Five paths on the row bands: four paths in one sweep, then the opposite horizontal path with the winner-take-all."""
