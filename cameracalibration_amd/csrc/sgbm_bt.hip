@@ -402,34 +402,35 @@ struct SelArgs {
     const int16_t* S; int H, W, W1, D, minD, minX1, uniq, maxDiff;
     int16_t* disp;
 };
-// One workgroup per image row: first-minimum WTA, uniqueness, disp2 election (minimum S, ties to
-// the larger x: the library walks right to left with a strict '>'), x16 parabola, then the
-// disp12MaxDiff check.  Columns left of minX1 stay invalid.
-#define BT_SEL_THREADS 1024      // sixteen waves per image row: the loop over a wave's pixels is a serial chain (wave-wide minimum, lane reads, LDS atomic)
+// One workgroup per image row.  First the waves walk the row's pixels (one pixel per wave and step): first-minimum WTA,
+// uniqueness, disp2 election (minimum S, ties to the larger x: the library walks right to left with a strict '>').  Only what
+// needs the whole wave stays in that serial loop; the x16 parabola of every pixel (an integer division) is done afterwards by
+// one lane per pixel, reading the two neighbours of the minimum back from S (the row was just read, so from the cache).  Then
+// the disp12MaxDiff check.  Columns left of minX1 stay invalid.
+#define BT_SEL_THREADS 1024      // sixteen waves per image row
+#ifndef BT_SEL_AHEAD
+#define BT_SEL_AHEAD 2
+#endif
 template <int ND>
 __global__ __launch_bounds__(BT_SEL_THREADS) void bt_select_kernel(SelArgs a)
 {
     constexpr int NWAVES = BT_SEL_THREADS / 64;
     extern __shared__ u32 lds[];
-    u32* key = lds;                                            // [W] (S + 32768) << 16 | (0xFFFF - x)
-    int16_t* d1 = reinterpret_cast<int16_t*>(lds + a.W);       // [W]
+    u32* key = lds;                  // [W] (S + 32768) << 16 | (0xFFFF - x)
+    u32* bst = lds + a.W;            // [W] winner of the pixel, (S + 32768) << 16 | k; later its disparity x16
     const int y = blockIdx.x, W = a.W, D = a.D;
     const int INVALID = (a.minD - 1) * 16;
-    for (int i = threadIdx.x; i < W; i += BT_SEL_THREADS) { key[i] = 0xFFFFFFFFu; d1[i] = (int16_t)INVALID; }
+    for (int i = threadIdx.x; i < W; i += BT_SEL_THREADS) { key[i] = 0xFFFFFFFFu; bst[i] = 0xFFFFFFFFu; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // lane l holds the ND consecutive sums l*ND .. l*ND+ND-1 of a pixel (one vector load); D is a multiple of 16 >= ND
     typedef typename CVec<ND>::type V;
     const int k0 = lane * ND;
     const bool mine = k0 < D;
-    V cur;
-    __builtin_memset(&cur, 0, sizeof(V));
-    if (mine && wv < a.W1) cur = *reinterpret_cast<const V*>(a.S + ((size_t)y * a.W1 + wv) * D + k0);
-    for (int x1 = wv; x1 < a.W1; x1 += NWAVES) {
-        const int16_t* sp = a.S + ((size_t)y * a.W1 + x1) * D;
+    const int q = 100 - a.uniq;      // the caller keeps |q| below 2^15: 24-bit multiplies below
+    auto decide = [&](int x1, const V& cur) {
         int16_t sv[ND];
         __builtin_memcpy(sv, &cur, sizeof(V));
-        if (mine && x1 + NWAVES < a.W1) cur = *reinterpret_cast<const V*>(sp + (size_t)NWAVES * D + k0);      // next pixel in flight
         u32 best = 0xFFFFFFFFu;
         if (mine) {
 #pragma unroll
@@ -437,38 +438,62 @@ __global__ __launch_bounds__(BT_SEL_THREADS) void bt_select_kernel(SelArgs a)
         }
         best = (u32)wave_min_dpp((int)(best ^ 0x80000000u)) ^ 0x80000000u;      // unsigned minimum through the signed reduction
         const int bk = (int)(best & 0xFFFF), minS = (int)(best >> 16) - 32768;
+        const int lim = minS * 100;
         bool bad = false;
         if (mine) {
 #pragma unroll
-            for (int j = 0; j < ND; j++) bad |= ((int)sv[j] * (100 - a.uniq) < minS * 100) && (abs(bk - (k0 + j)) > 1);
+            for (int j = 0; j < ND; j++) bad |= (__mul24((int)sv[j], q) < lim) && ((u32)(k0 + j - bk + 1) > 2u);
         }
-        if (__any(bad)) continue;
-        // the neighbours of the minimum for the parabola, from the registers that hold them (the minimum is the same in
-        // every lane, so lane and register index are wave-uniform): no dependent memory access in this serial loop
-        auto s_at = [&](int k) -> int {
-            const int kk = __builtin_amdgcn_readfirstlane(min(max(k, 0), D - 1));
-            int v = 0;
-#pragma unroll
-            for (int j = 0; j < ND; j++)
-                if (j == kk % ND) v = sv[j];
-            return __builtin_amdgcn_readlane(v, kk / ND);
-        };
-        const int sm = s_at(bk - 1), spl = s_at(bk + 1);
+        if (__any(bad)) return;
         if (lane == 0) {
-            int d = bk;
-            const int x = x1 + a.minX1, x2 = x - d - a.minD;
+            const int x = x1 + a.minX1, x2 = x - bk - a.minD;
             atomicMin(&key[x2], ((best >> 16) << 16) | (u32)(0xFFFF - x));
-            if (d > 0 && d < D - 1) {
-                const int s0 = minS;
-                const int den = max(sm + spl - 2 * s0, 1);
-                d = d * 16 + ((sm - spl) * 16 + den) / (den * 2);
-            } else d *= 16;
-            d1[x] = (int16_t)(d + a.minD * 16);
+            bst[x] = best;
         }
+    };
+    // the sums of the wave's next BT_SEL_AHEAD pixels are in flight while one pixel is decided (requests are unconditional:
+    // lanes beyond D ask for the first lane's values, steps beyond the row's end for its last pixel again)
+    if (a.W1 > 0) {
+        const int16_t* const srow = a.S + (size_t)y * a.W1 * D + (mine ? k0 : 0);
+        auto request = [&](int i) { return *reinterpret_cast<const V*>(srow + (size_t)min(wv + i * NWAVES, a.W1 - 1) * D); };
+        const int n = wv < a.W1 ? (a.W1 - wv + NWAVES - 1) / NWAVES : 0;      // pixels of this wave: x1 = wv + i * NWAVES
+        V ring[BT_SEL_AHEAD];
+#pragma unroll
+        for (int u = 0; u < BT_SEL_AHEAD; u++) ring[u] = request(u);
+        // whole groups of BT_SEL_AHEAD pixels without an exit in the middle, so the ring keeps its registers
+        int i = 0;
+        for (; i + BT_SEL_AHEAD <= n; i += BT_SEL_AHEAD) {
+#pragma unroll
+            for (int u = 0; u < BT_SEL_AHEAD; u++) {
+                const V cur = ring[u];
+                ring[u] = request(i + u + BT_SEL_AHEAD);
+                decide(wv + (i + u) * NWAVES, cur);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BT_SEL_AHEAD; u++)
+            if (i + u < n) decide(wv + (i + u) * NWAVES, ring[u]);
     }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += BT_SEL_THREADS) {
-        int v = d1[x];
+        const u32 b = bst[x];
+        int v = INVALID;
+        if (b != 0xFFFFFFFFu) {
+            const int bk = (int)(b & 0xFFFF), s0 = (int)(b >> 16) - 32768;
+            int d = bk * 16;
+            if (bk > 0 && bk < D - 1) {
+                const int16_t* sp = a.S + ((size_t)y * a.W1 + (x - a.minX1)) * D + bk;
+                const int sm = sp[-1], spl = sp[1];
+                const int den = max(sm + spl - 2 * s0, 1);
+                d += ((sm - spl) * 16 + den) / (den * 2);
+            }
+            v = d + a.minD * 16;
+        }
+        bst[x] = (u32)(int)(int16_t)v;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += BT_SEL_THREADS) {
+        int v = (int)bst[x];
         if (v != INVALID && x >= a.minX1) {
             auto inconsistent = [&](int xx, int dd) -> bool {
                 if (xx < 0 || xx >= W) return false;
@@ -634,6 +659,8 @@ static int validate(int H, int W, int cn, const mdisp_stereosgbm_params* p)
                "StereoSGBM mode %d is not built (MODE_SGBM and MODE_HH are)", p->mode);
     MD_REQUIRE((p->blockSize <= 0 || p->blockSize % 2 == 1) && p->blockSize <= 31, MDISP_E_BADARG, "blockSize must be odd (at most 31)");
     MD_REQUIRE((size_t)H * W < ((size_t)1 << 30), MDISP_E_RANGE, "image too large");
+    // S * (100 - uniquenessRatio) is a 32-bit product in the library (S is a 16-bit sum); it is evaluated with 24-bit operands here
+    MD_REQUIRE(p->uniquenessRatio <= 32767, MDISP_E_RANGE, "uniquenessRatio above 32767 is not supported");
     return MDISP_OK;
 }
 
@@ -664,12 +691,12 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
         // (the median and speckle stages keep it constant)
         SelArgs sa{};
         sa.S = nullptr; sa.H = H; sa.W = W; sa.W1 = 0; sa.D = g.D; sa.minD = g.minD; sa.minX1 = W; sa.uniq = 0; sa.maxDiff = 1; sa.disp = dDisp;
-        bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
+        bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
         MD_HIP(hipGetLastError());
         if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, dDisp, N * 2, hipMemcpyDeviceToDevice, s));
         return MDISP_OK;
     }
-    MD_REQUIRE((size_t)W * 6 + 16 <= 64 * 1024, MDISP_E_RANGE, "image wider than 10900 columns");
+    MD_REQUIRE((size_t)W * 8 + 16 <= 64 * 1024, MDISP_E_RANGE, "image wider than 8190 columns");
     const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
@@ -750,10 +777,10 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     sa.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
     sa.maxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     sa.disp = raw;
-    if (nd == 1) bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
-    else if (nd == 2) bt_select_kernel<2><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
-    else if (nd == 4) bt_select_kernel<4><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
-    else bt_select_kernel<8><<<H, BT_SEL_THREADS, (size_t)W * 6 + 16, s>>>(sa);
+    if (nd == 1) bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
+    else if (nd == 2) bt_select_kernel<2><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
+    else if (nd == 4) bt_select_kernel<4><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
+    else bt_select_kernel<8><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
     MD_HIP(hipGetLastError());
     if (dRaw) MD_HIP(hipMemcpyAsync(dRaw, raw, N * 2, hipMemcpyDeviceToDevice, s));
     const bool speckle = p->speckleWindowSize > 0;

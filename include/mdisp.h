@@ -137,7 +137,7 @@ typedef struct mdisp_stereosgbm_params {
     int P1, P2;             /* <= 0 select 2 and 5; P2 is raised to P1 + 1                         */
     int disp12MaxDiff;      /* <= 0 selects 1                                                      */
     int preFilterCap;       /* clip of the x-Sobel response: max(preFilterCap, 15) | 1             */
-    int uniquenessRatio;    /* < 0 selects 10                                                      */
+    int uniquenessRatio;    /* < 0 selects 10; above 32767: MDISP_E_RANGE                          */
     int speckleWindowSize;  /* 0 disables the speckle filter                                       */
     int speckleRange;
     int mode;               /* MDISP_SGBM_MODE_*                                                   */
