@@ -240,6 +240,8 @@ template <> struct AccVec<int, 8> { typedef bt_int8 type; };
 struct PathArgs {
     const int16_t* C; void* acc; int H, W1, D, P1, P2; int16_t* S; int firstGroup;
     int mdx[4], mdy[4], mfirst[5];        // MULTI: the directions of one launch and the first line index of each
+    const void* accIn;                    // the group's sum so far (read); `acc` receives the new sum
+    void* opp;                            // OPP: the path values of the direction opposite to the launch's own
 };
 
 // cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
@@ -264,17 +266,23 @@ __device__ __forceinline__ int wave_min_dpp(int v)
 // MULTI: one launch runs the lines of all directions of a group side by side and adds their values into a zeroed
 // int32 `acc` with atomics (integer sums do not depend on the order) -- for small problems, where a single direction
 // has too few lines to fill the GPU and the serial recursion of each line sets the time.
-template <int ND, bool FIRST, bool LAST = false, class AccT = int, bool MULTI = false>
+// OPP (large problems, 16-bit sums): a horizontal direction has one line per image row, about one wave per SIMD, and takes
+// the time of its serial chain whatever else runs.  With FIRST, the launch therefore runs the opposite direction as well, on
+// as many more waves (lines nlines .. 2 * nlines - 1), and keeps its path values in `opp`.  With LAST, `opp` is added
+// after the group's own sum: S = saturate(saturate(S + acc + L) + opp), the sum the next group would have formed.
+template <int ND, bool FIRST, bool LAST = false, class AccT = int, bool MULTI = false, bool OPP = false>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
-    AccT* const accp = static_cast<AccT*>(a.acc);
+    AccT* accp = static_cast<AccT*>(a.acc);
+    const AccT* const accInp = static_cast<const AccT*>(a.accIn);
     // every element of S is read (several steps ahead) and later written by the same lane and by nobody else
     const int16_t* __restrict__ Sin = a.S;
     int16_t* __restrict__ Sout = a.S;
     const int lane = threadIdx.x & 63;
     // the line is the same for every lane of a wave: kept in a scalar register, so that the loop bounds are uniform
     int line = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (line >= nlines) return;
+    if (line >= (OPP && FIRST ? 2 * nlines : nlines)) return;
+    if (OPP && FIRST && line >= nlines) { line -= nlines; dx = -dx; dy = -dy; accp = static_cast<AccT*>(a.opp); }
     if (MULTI) {
         int i = 0;
         while (i < 3 && line >= a.mfirst[i + 1]) i++;
@@ -307,15 +315,16 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     // into every step.
     constexpr int PF = ND <= 2 ? 16 : 8;
     typedef typename AccVec<AccT, ND>::type AV;
-    struct In { V c; V sOld; AV old; };
+    struct In { V c; V sOld; AV old; AV opp; };
     In ring[PF];
     const int kl = mine ? k0 : 0;
     auto fetch = [&](int t, In& in) {
         const int tf = min(t, n - 1);
         const size_t o = ((size_t)(y0 + tf * dy) * W + (x0 + tf * dx)) * D + kl;
         in.c = *reinterpret_cast<const V*>(a.C + o);
-        if (!FIRST) in.old = *reinterpret_cast<const AV*>(accp + o);
+        if (!FIRST) in.old = *reinterpret_cast<const AV*>(accInp + o);
         if (LAST && !a.firstGroup) in.sOld = *reinterpret_cast<const V*>(Sin + o);
+        if (OPP && LAST) in.opp = *reinterpret_cast<const AV*>(static_cast<const AccT*>(a.opp) + o);
     };
 #pragma unroll
     for (int u = 0; u < PF; u++) fetch(u, ring[u]);
@@ -355,6 +364,12 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 for (int j = 0; j < ND; j++) {
                     const int v = (a.firstGroup ? 0 : (int)sv[j]) + old[j] + Ln[j];
                     sv[j] = (int16_t)min(max(v, -32768), 32767);
+                }
+                if (OPP) {
+                    AccT ov[ND];
+                    __builtin_memcpy(ov, &in.opp, sizeof(AV));
+#pragma unroll
+                    for (int j = 0; j < ND; j++) sv[j] = (int16_t)min(max((int)sv[j] + (int)ov[j], -32768), 32767);
                 }
                 V packed;
                 __builtin_memcpy(&packed, sv, sizeof(V));
@@ -716,7 +731,8 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     MD_HIP(hipGetLastError());
     if (dCost) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
     static const int DIRS[8][2] = {{+1, 0}, {+1, +1}, {0, +1}, {-1, +1}, {-1, 0}, {-1, -1}, {0, -1}, {+1, -1}};
-    PathArgs pa{v0, acc, H, g.W1, g.D, P1, P2, S, 1};
+    PathArgs pa{};
+    pa.C = v0; pa.acc = acc; pa.accIn = acc; pa.opp = v1; pa.H = H; pa.W1 = g.W1; pa.D = g.D; pa.P1 = P1; pa.P2 = P2; pa.S = S; pa.firstGroup = 1;
     const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
     // a path value lies in [-P2, Cmax]; three of them fit int16 when the block cost cannot exceed 10922 (then it cannot
     // have wrapped either): block cost <= bs^2 * cn * (2 * ftzero + 255 / 4)
@@ -755,13 +771,23 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             bt_saturate_kernel<<<nblk(V), 256, 0, s>>>(acc, V, grp == 0, S);
             continue;
         }
+        // 16-bit sums: the first group's -> launch runs <- beside it (the first direction of the second group) and keeps its
+        // values in the buffer the horizontal window sums no longer need
+        const bool opp = acc16;
         for (int i = 0; i < ndir; i++) {
             const int dx = DIRS[grp * 4 + i][0], dy = DIRS[grp * 4 + i][1];
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
-            const dim3 gp((nlines + 3) / 4);
+            dim3 gp((nlines + 3) / 4);
+            if (opp && grp == 1 && i == 0) continue;                     // <- ran beside ->
+            const bool oppFirst = opp && grp == 0 && i == 0;
+            const bool oppLast = opp && grp == 0 && i == ndir - 1 && p->mode == MDISP_SGBM_MODE_SGBM;      // MODE_SGBM: <- is all of the second group
+            pa.accIn = (opp && grp == 1 && i == 1) ? (const void*)v1 : (const void*)acc;
+            if (oppFirst) gp = dim3((2 * nlines + 3) / 4);
 #define BT_PATH(NDV, ACC)                                                                                      \
             do {                                                                                               \
-                if (ndir == 1) bt_path_kernel<NDV, true, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
+                if (oppFirst) bt_path_kernel<NDV, true, false, ACC, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);          \
+                else if (oppLast) bt_path_kernel<NDV, false, true, ACC, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);      \
+                else if (ndir == 1) bt_path_kernel<NDV, true, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
                 else if (i == 0) bt_path_kernel<NDV, true, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
                 else if (i == ndir - 1) bt_path_kernel<NDV, false, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
                 else bt_path_kernel<NDV, false, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                \
