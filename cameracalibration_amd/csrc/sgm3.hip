@@ -43,6 +43,10 @@ namespace {
 constexpr int sgm3_waves_per_simd(int lpc, int nrt, bool tail, bool s4b, bool s16, int role)
 { return (lpc == 16 && nrt == 16) || s16 ? 2 : (nrt == 8 && !tail && s4b ? (role == 0 ? SGM3_WPS0 : 5) : 4); }
 
+// compute lanes of a workgroup at 16 lanes x 16 disparities per pixel
+#ifndef SGM3_NT16
+#define SGM3_NT16 256
+#endif
 struct RowArgs {
     Sgm2Args a;
     u8* hand;               // [B][ring][W][3][state bytes]: states (v, \, /) of the last row of a band, per pixel; band b uses entry b & ringMask
@@ -61,7 +65,14 @@ struct RowArgs {
     // bands each direction sweeps first, and one word per direction, pair and band that is set when the band's four-path
     // sums are in memory
     u8* handUp; int vofsUp; int firstDown, firstUp; int* done;
+#ifdef SGM3_TRACE
+    int traceIdx;
+#endif
 };
+#ifdef SGM3_TRACE
+#define SGM3_TRACE_MAX (1 << 16)
+__device__ unsigned long long g_trace[SGM3_TRACE_MAX][4];      // per ticket: start, ready, end, ticks the communication wave waited
+#endif
 
 // LPC lanes share a pixel, each with NRT packed registers (2 NRT disparities); NT compute lanes per workgroup.
 // Byte images of a pixel (LDS states, hand-off rows, byte four-path sums) are stored as NRT/8 planes of LPC*16 bytes:
@@ -138,6 +149,9 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
             const int need = min(i + 2 + ra.slack, W);    // pixels the band above must have published (two, plus the slack that decouples the bands)
             if (seen < need) {
                 unsigned long long t0 = 0;
+#ifdef SGM3_TRACE
+                const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 for (int it = 0;; it++) {
                     seen = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (seen >= need) break;
@@ -159,6 +173,9 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
                     else __builtin_amdgcn_s_sleep(64);
                 }
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#ifdef SGM3_TRACE
+                if (COH && lane == 0) g_trace[ra.traceIdx][3] += __builtin_amdgcn_s_memrealtime() - tw0;
+#endif
             }
             if (mine) {
                 const u32 src = hand_slot(band - 1, i + 1, which);
@@ -489,6 +506,9 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, 
     init_excl_mask_n<NRT>(exclMask);
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+#ifdef SGM3_TRACE
+    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) { g_trace[ticket][0] = __builtin_amdgcn_s_memrealtime(); g_trace[ticket][3] = 0; }
+#endif
     // inside a band step the direction that sweeps first over more bands comes first: with an odd number of bands the middle
     // band is that direction's last first-sweep band and the other direction's first second-sweep band
     const int perStep = 2 * ra.batch, band = ticket / perStep, r = ticket - band * perStep;
@@ -516,11 +536,18 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, 
         __syncthreads();
     }
     RowArgs rl = ra;
+#ifdef SGM3_TRACE
+    rl.traceIdx = ticket < SGM3_TRACE_MAX ? ticket : 0;
+    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) g_trace[ticket][1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (up) { rl.hand = ra.handUp; rl.vofs = ra.vofsUp; }
     if (!up && !second) sgm3_rows_body<false, 0, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
     else if (up && !second) sgm3_rows_body<true, 0, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
     else if (up) sgm3_rows_body<true, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
     else sgm3_rows_body<false, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
+#ifdef SGM3_TRACE
+    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) g_trace[ticket][2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int LPC, int NRT, int NT, bool BOTH, bool FOUR = false>
@@ -553,8 +580,8 @@ int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int rol
     const dim3 g((unsigned)nbands * ra.batch);
 #define SGM3_ROLE16(UPV, ROLEV)                                                                           \
     do {                                                                                                  \
-        if (tail) sgm3_rows_kernel<UPV, ROLEV, true, false, 16, 8, 256, true, FOUR><<<g, 256 + 64, 0, s>>>(ra);   \
-        else sgm3_rows_kernel<UPV, ROLEV, false, false, 16, 8, 256, true, FOUR><<<g, 256 + 64, 0, s>>>(ra);       \
+        if (tail) sgm3_rows_kernel<UPV, ROLEV, true, false, 16, 8, SGM3_NT16, true, FOUR><<<g, SGM3_NT16 + 64, 0, s>>>(ra);   \
+        else sgm3_rows_kernel<UPV, ROLEV, false, false, 16, 8, SGM3_NT16, true, FOUR><<<g, SGM3_NT16 + 64, 0, s>>>(ra);       \
     } while (0)
     if (!up && role == 0) SGM3_ROLE16(false, 0);
     else if (up && role == 1) SGM3_ROLE16(true, 1);
@@ -572,7 +599,7 @@ int launch_rows16(hipStream_t s, const RowArgs& ra, int nbands, bool up, int rol
 
 // geometry of the row-band kernels: a pixel has lpc lanes x dpl disparity slots; compute lanes per workgroup (512 slots
 // per pixel: eight rows per band, so that the states and the winner-take-all rows of a band fit the 64 KB of static LDS)
-int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : 256; }
+int md_sgm3_lanes(int lpc, int dpl) { return lpc == 16 && dpl == 32 ? 128 : lpc == 16 ? SGM3_NT16 : 256; }
 // bands of the image: one more than the rows need, because the mirrored sweep pads its first band so that band edges fall
 // on the same image rows in both directions
 int md_sgm3_bands(int H, int lpc, int nt) { const int rows = nt / lpc; return (H + rows - 1) / rows; }
@@ -632,11 +659,11 @@ int md_sgm3_sweep(hipStream_t s, const Sgm2Args& a, u8* hand, size_t strideHand,
     }
     if (a.four) {
         MD_REQUIRE(lpc == 16 && dpl == 16, MDISP_E_UNSUPPORTED, "row bands: the 4-path mode is built for 16 lanes x 16 disparities");
-        return launch_rows<16, 8, 256, true, true>(s, ra, nbands, up, role, s4b, tail);
+        return launch_rows<16, 8, SGM3_NT16, true, true>(s, ra, nbands, up, role, s4b, tail);
     }
     if (lpc == 4) return launch_rows<4, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
     if (lpc == 8) return launch_rows<8, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
-    return launch_rows<16, 8, 256, true>(s, ra, nbands, up, role, s4b, tail);
+    return launch_rows<16, 8, SGM3_NT16, true>(s, ra, nbands, up, role, s4b, tail);
 }
 
 // Both sweeps over all bands of `batch` pairs (down first); `sync` must be zero.  The two sweeps may share one hand-off ring.
@@ -658,7 +685,7 @@ bool md_sgm3_meet_supported(const Sgm2Args& a, int lpc, int dpl, bool s4b, bool 
 int md_sgm3_meet(hipStream_t s, const Sgm2Args& a, u8* handDown, u8* handUp, size_t strideHand, int* sync, int* err, int batch, int lpc, int dpl, int nt,
                  int firstDown, int firstUp)
 {
-    MD_REQUIRE(md_sgm3_meet_supported(a, lpc, dpl, true, false) && nt == 256, MDISP_E_UNSUPPORTED, "row bands: the one-launch schedule is not built for this geometry");
+    MD_REQUIRE(md_sgm3_meet_supported(a, lpc, dpl, true, false) && nt == SGM3_NT16, MDISP_E_UNSUPPORTED, "row bands: the one-launch schedule is not built for this geometry");
     RowArgs ra;
     ra.a = a; ra.hand = handDown; ra.handUp = handUp; ra.strideHand = strideHand; ra.sync = sync; ra.err = err;
     const int rows = nt / lpc;
@@ -675,7 +702,14 @@ int md_sgm3_meet(hipStream_t s, const Sgm2Args& a, u8* handDown, u8* handUp, siz
     MD_REQUIRE(strideHand < ((size_t)1 << 32), MDISP_E_RANGE, "row bands: hand-off ring of %zu bytes per pair exceeds 4 GB", strideHand);
     { const int sl = md_tune(MDISP_TUNE_SGM_BAND_SLACK); ra.slack = sl > 0 ? sl : 0; }
     const dim3 g((unsigned)(2 * ra.nb) * batch);
-    sgm3_meet_kernel<false, 16, 8, 256><<<g, 256 + 64, 0, s>>>(ra);
+    sgm3_meet_kernel<false, 16, 8, SGM3_NT16><<<g, SGM3_NT16 + 64, 0, s>>>(ra);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }
+
+#ifdef SGM3_TRACE
+extern "C" int md_sgm3_trace_read(void* out, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), bytes < sizeof(g_trace) ? bytes : sizeof(g_trace));
+}
+#endif
