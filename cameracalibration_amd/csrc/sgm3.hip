@@ -71,7 +71,7 @@ struct RowArgs {
 };
 #ifdef SGM3_TRACE
 #define SGM3_TRACE_MAX (1 << 16)
-__device__ unsigned long long g_trace[SGM3_TRACE_MAX][4];      // per ticket: start, ready, end, ticks the communication wave waited
+__device__ unsigned long long g_trace[SGM3_TRACE_MAX][6];      // per ticket: start, ready, end, ticks the communication wave waited (100 MHz clock); shader clock at start and end
 #endif
 
 // LPC lanes share a pixel, each with NRT packed registers (2 NRT disparities); NT compute lanes per workgroup.
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, 
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
 #ifdef SGM3_TRACE
-    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) { g_trace[ticket][0] = __builtin_amdgcn_s_memrealtime(); g_trace[ticket][3] = 0; }
+    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) { g_trace[ticket][0] = __builtin_amdgcn_s_memrealtime(); g_trace[ticket][3] = 0; g_trace[ticket][4] = __builtin_amdgcn_s_memtime(); }
 #endif
     // inside a band step the direction that sweeps first over more bands comes first: with an odd number of bands the middle
     // band is that direction's last first-sweep band and the other direction's first second-sweep band
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, 
     else if (up) sgm3_rows_body<true, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
     else sgm3_rows_body<false, 1, TAIL, true, LPC, NRT, NT, false, false, true>(rl, band, pair, st, srow, exclMask);
 #ifdef SGM3_TRACE
-    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) g_trace[ticket][2] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) { g_trace[ticket][2] = __builtin_amdgcn_s_memrealtime(); g_trace[ticket][5] = __builtin_amdgcn_s_memtime(); }
 #endif
 }
 

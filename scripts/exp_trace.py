@@ -29,7 +29,7 @@ for _ in range(3):
     ctx.synchronize()
 nb = (H + 15) // 16
 n = 2 * nb * B
-buf = np.zeros((n, 4), np.uint64)
+buf = np.zeros((n, 6), np.uint64)
 raw = C.CDLL(_lib.LIB_PATH)
 raw.md_sgm3_trace_read.argtypes = [C.c_void_p, C.c_size_t]
 assert raw.md_sgm3_trace_read(buf.ctypes.data, buf.nbytes) == 0
@@ -37,6 +37,10 @@ t = buf.astype(np.float64) / 100.0     # microseconds (100 MHz counter)
 t0 = t[:, 0].min()
 start, ready, end, wait = t[:, 0] - t0, t[:, 1] - t0, t[:, 2] - t0, t[:, 3]
 total = end.max()
+ticks = (buf[:, 2] - buf[:, 0]).astype(np.float64)
+cyc = (buf[:, 5] - buf[:, 4]).astype(np.float64)
+mhz = cyc / ticks * 100.0
+print("shader clock while a band runs (shader cycles per 100 MHz tick): mean %.0f MHz  p10 %.0f  p90 %.0f" % (mhz.mean(), *np.percentile(mhz, [10, 90])))
 print("pairs %d  tickets %d  kernel span %.2f ms" % (B, n, total / 1e3))
 dur = end - ready
 print("band duration (ready -> end): mean %.0f us  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % (dur.mean(), *np.percentile(dur, [10, 50, 90]), dur.max()))
