@@ -34,6 +34,8 @@ CASES = [
     (300, 100, 1, (0, 32, 9, 50, 400, 1, 31, 10, 60, 2, 1)),               # several marching bands per column
     (40, 120, 1, (0, 32, 5, 20, 100, 1, 31, 99, 0, 0, 1)),                 # uniqueness test that nearly every pixel fails
     (40, 120, 1, (0, 32, 5, 20, 100, 1, 31, 130, 0, 0, 0)),                # 100 - uniquenessRatio negative
+    (24, 340, 1, (0, 272, 5, 30, 200, 1, 31, 10, 0, 0, 1)),                # more than 256 disparities: eight per lane
+    (24, 340, 1, (0, 272, 5, 30, 200, 1, 31, 10, 0, 0, 0)),
 ]
 
 
