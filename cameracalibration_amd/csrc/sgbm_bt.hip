@@ -602,7 +602,9 @@ __global__ __launch_bounds__(256) void speckle_link_kernel(const int16_t* __rest
         }
     }
 }
-__global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __restrict__ img, int n, int newVal, int* parent, int* count)
+// Only "at most maxSize pixels or more" is needed, so a run stops adding once its region's count is beyond maxSize: a large
+// region is thousands of runs whose atomics would otherwise queue on one word.
+__global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __restrict__ img, int n, int newVal, int maxSize, int* parent, int* count)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     int r = -1;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(256) void speckle_count_kernel(const int16_t* __res
     if (head && r >= 0) {
         const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
         const int len = after ? __ffsll((long long)after) : 64 - lane;
-        atomicAdd(count + r, len);
+        if (__hip_atomic_load(count + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= maxSize) atomicAdd(count + r, len);
     }
 }
 __global__ __launch_bounds__(256) void speckle_apply_kernel(int16_t* __restrict__ img, int n, int newVal, int maxSize, const int* __restrict__ parent,
@@ -649,7 +651,7 @@ int md_filter_speckles_s16(hipStream_t s, int16_t* img, int H, int W, int newVal
     int* count = (int*)((u8*)scratch + md_align((size_t)n * 4, 256));
     speckle_init_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(img, W, newVal, maxDiff, parent, count);
     speckle_link_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(img, H, W, newVal, maxDiff, parent);
-    speckle_count_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, parent, count);
+    speckle_count_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, maxSize, parent, count);
     speckle_apply_kernel<<<nblk(n), 256, 0, s>>>(img, n, newVal, maxSize, parent, count);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
