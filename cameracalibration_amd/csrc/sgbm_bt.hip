@@ -101,6 +101,37 @@ __global__ __launch_bounds__(256) void bt_window_kernel(const int16_t* __restric
     out[((size_t)y * g.W1 + x1) * g.D + k] = (int16_t)s;
 }
 
+// Which accesses of the cost / path volumes are marked non-temporal (streamed once, far larger than the caches), as measured at
+// 1920 x 1080 x 256: 1 | 2 the scan-line kernels' loads and stores (3.94 -> 3.85 ms; either alone is slower), 8 the stores of the
+// horizontal sums (-> 3.82); not 4, the vertical sum (it reads every row twice, bs rows apart: 3.96), 16 the selection (no change).
+#ifndef BT_NT
+#define BT_NT 11
+#endif
+typedef u32 bt_u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 bt_u32x4 __attribute__((ext_vector_type(4)));
+template <int BIT = 1, class T> __device__ __forceinline__ T bt_ld(const T* p)
+{
+    if constexpr ((BT_NT & BIT) == 0) return *p;
+    else {
+        T r;
+        if constexpr (sizeof(T) == 2) { const unsigned short v = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p)); __builtin_memcpy(&r, &v, 2); }
+        else if constexpr (sizeof(T) == 4) { const u32 v = __builtin_nontemporal_load(reinterpret_cast<const u32*>(p)); __builtin_memcpy(&r, &v, 4); }
+        else if constexpr (sizeof(T) == 8) { const bt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const bt_u32x2*>(p)); __builtin_memcpy(&r, &v, 8); }
+        else if constexpr (sizeof(T) == 16) { const bt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bt_u32x4*>(p)); __builtin_memcpy(&r, &v, 16); }
+        else { static_assert(sizeof(T) == 32, "size"); const bt_u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const bt_u32x4*>(p)); const bt_u32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const bt_u32x4*>(p) + 1); __builtin_memcpy(&r, &v0, 16); __builtin_memcpy(reinterpret_cast<char*>(&r) + 16, &v1, 16); }
+        return r;
+    }
+}
+template <int BIT = 2, class T> __device__ __forceinline__ void bt_st(T* p, const T& val)
+{
+    if constexpr ((BT_NT & BIT) == 0) *p = val;
+    else {
+        if constexpr (sizeof(T) == 2) { unsigned short v; __builtin_memcpy(&v, &val, 2); __builtin_nontemporal_store(v, reinterpret_cast<unsigned short*>(p)); }
+        else if constexpr (sizeof(T) == 4) { u32 v; __builtin_memcpy(&v, &val, 4); __builtin_nontemporal_store(v, reinterpret_cast<u32*>(p)); }
+        else if constexpr (sizeof(T) == 8) { bt_u32x2 v; __builtin_memcpy(&v, &val, 8); __builtin_nontemporal_store(v, reinterpret_cast<bt_u32x2*>(p)); }
+        else { static_assert(sizeof(T) == 16, "size"); bt_u32x4 v; __builtin_memcpy(&v, &val, 16); __builtin_nontemporal_store(v, reinterpret_cast<bt_u32x4*>(p)); }
+    }
+}
 // Pixel cost and horizontal window sum in one pass: a workgroup holds the plane rows of image row y in LDS, lane k
 // marches along the computed columns with a running sum (entering column - leaving column, both with the window
 // clamped to the computed columns), so the pixel costs never reach memory.  Same values as bt_cost_kernel followed by
@@ -168,14 +199,14 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
         slotEnter = slotEnter + 1 == R ? 0 : slotEnter + 1;
     }
     int16_t* o = out + (size_t)y * W1 * g.D + k;
-    o[(size_t)xa * g.D] = (int16_t)s;
+    bt_st<8>(o + (size_t)xa * g.D, (int16_t)s);
     for (int x1 = xa + 1; x1 < xb; x1++) {
         const int enter = pix(min(x1 + h, W1 - 1));
         s += enter - (int)ring[slotLeave * 256];
         ring[slotEnter * 256] = (int16_t)enter;
         slotEnter = slotEnter + 1 == R ? 0 : slotEnter + 1;
         slotLeave = slotLeave + 1 == R ? 0 : slotLeave + 1;
-        o[(size_t)x1 * g.D] = (int16_t)s;
+        bt_st<8>(o + (size_t)x1 * g.D, (int16_t)s);
     }
 }
 
@@ -191,13 +222,13 @@ __global__ __launch_bounds__(256) void bt_vsum_kernel(const int16_t* __restrict_
     const bool frozen = e < (size_t)g.D;                 // x1 == 0: row 0's sum everywhere
     const int ya = blockIdx.y * BT_VBAND, yb = min(ya + BT_VBAND, H), yc = frozen ? 0 : ya;
     auto load4 = [&](int y, int (&v)[4]) {
-        const uint2 w = *reinterpret_cast<const uint2*>(in + (size_t)y * rowN + e);
+        const uint2 w = bt_ld<4>(reinterpret_cast<const uint2*>(in + (size_t)y * rowN + e));
         v[0] = (int16_t)(w.x & 0xFFFFu); v[1] = (int16_t)(w.x >> 16); v[2] = (int16_t)(w.y & 0xFFFFu); v[3] = (int16_t)(w.y >> 16);
     };
     auto store4 = [&](int y, const int (&v)[4]) {
         uint2 w;
         w.x = ((u32)v[0] & 0xFFFFu) | ((u32)v[1] << 16); w.y = ((u32)v[2] & 0xFFFFu) | ((u32)v[3] << 16);
-        *reinterpret_cast<uint2*>(out + (size_t)y * rowN + e) = w;
+        bt_st<4>(reinterpret_cast<uint2*>(out + (size_t)y * rowN + e), w);
     };
     int s[4] = {0, 0, 0, 0};
     for (int i = -h; i <= h; i++) {
@@ -321,10 +352,10 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     auto fetch = [&](int t, In& in) {
         const int tf = min(t, n - 1);
         const size_t o = ((size_t)(y0 + tf * dy) * W + (x0 + tf * dx)) * D + kl;
-        in.c = *reinterpret_cast<const V*>(a.C + o);
-        if (!FIRST) in.old = *reinterpret_cast<const AV*>(accInp + o);
-        if (LAST && !a.firstGroup) in.sOld = *reinterpret_cast<const V*>(Sin + o);
-        if (OPP && LAST) in.opp = *reinterpret_cast<const AV*>(static_cast<const AccT*>(a.opp) + o);
+        in.c = bt_ld(reinterpret_cast<const V*>(a.C + o));
+        if (!FIRST) in.old = bt_ld(reinterpret_cast<const AV*>(accInp + o));
+        if (LAST && !a.firstGroup) in.sOld = bt_ld(reinterpret_cast<const V*>(Sin + o));
+        if (OPP && LAST) in.opp = bt_ld(reinterpret_cast<const AV*>(static_cast<const AccT*>(a.opp) + o));
     };
 #pragma unroll
     for (int u = 0; u < PF; u++) fetch(u, ring[u]);
@@ -373,15 +404,24 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 }
                 V packed;
                 __builtin_memcpy(&packed, sv, sizeof(V));
-                *reinterpret_cast<V*>(Sout + o) = packed;
+                bt_st(reinterpret_cast<V*>(Sout + o), packed);
             } else if (MULTI) {
                 int* ap = static_cast<int*>(a.acc) + o;
 #pragma unroll
                 for (int j = 0; j < ND; j++) atomicAdd(ap + j, Ln[j]);
             } else {
-                AccT* ap = accp + o;
+                AccT av[ND];
 #pragma unroll
-                for (int j = 0; j < ND; j++) ap[j] = (AccT)(old[j] + Ln[j]);
+                for (int j = 0; j < ND; j++) av[j] = (AccT)(old[j] + Ln[j]);
+                if constexpr (sizeof(AV) <= 16) {
+                    AV packedAcc;
+                    __builtin_memcpy(&packedAcc, av, sizeof(AV));
+                    bt_st(reinterpret_cast<AV*>(accp + o), packedAcc);
+                } else {
+                    AccT* ap = accp + o;
+#pragma unroll
+                    for (int j = 0; j < ND; j++) ap[j] = av[j];
+                }
             }
         }
 #pragma unroll
@@ -470,7 +510,7 @@ __global__ __launch_bounds__(BT_SEL_THREADS) void bt_select_kernel(SelArgs a)
     // lanes beyond D ask for the first lane's values, steps beyond the row's end for its last pixel again)
     if (a.W1 > 0) {
         const int16_t* const srow = a.S + (size_t)y * a.W1 * D + (mine ? k0 : 0);
-        auto request = [&](int i) { return *reinterpret_cast<const V*>(srow + (size_t)min(wv + i * NWAVES, a.W1 - 1) * D); };
+        auto request = [&](int i) { return bt_ld<16>(reinterpret_cast<const V*>(srow + (size_t)min(wv + i * NWAVES, a.W1 - 1) * D)); };
         const int n = wv < a.W1 ? (a.W1 - wv + NWAVES - 1) / NWAVES : 0;      // pixels of this wave: x1 = wv + i * NWAVES
         V ring[BT_SEL_AHEAD];
 #pragma unroll
