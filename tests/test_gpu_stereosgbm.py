@@ -64,6 +64,23 @@ def test_stereosgbm_bit_exact(api, orc, case, bt_schedule):
     assert np.array_equal(api.stereosgbm_compute(L, R, p), exp)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_stereosgbm_full_size_frame_bit_exact(api, orc, mode):
+    """1920 x 1080, 256 disparities, the reference's parameter set: the schedule large problems take by themselves (one launch
+    per direction, the two horizontal directions sharing a launch, 16-bit group sums), map before and after the median and
+    speckle filters."""
+    from cameracalibration_amd import _lib
+    _lib.tuning_reset()
+    H, W, D = 1080, 1920, 256
+    L, R, _ = api.synth_pair(0x5EED0001, H, W, D)
+    args = (0, D, 7, 490, 1960, 1, 63, 10, 100, 32, mode)
+    got, raw = api.stereosgbm_compute(L, R, api.StereoSGBM_create(*args), want_raw=True)
+    exp, eraw = orc.sgbm_bt(L, R, *args, want_raw=True)
+    assert np.array_equal(raw, eraw)
+    assert np.array_equal(got, exp)
+    assert (got[:, D:] >= 0).mean() > 0.5
+
+
 def test_stereosgbm_rejects_a_uniqueness_ratio_beyond_16_bits(api):
     from cameracalibration_amd._lib import MdispError, E_RANGE
     L, R = _pair(api, 5, 20, 80, 8)
