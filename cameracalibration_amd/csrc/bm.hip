@@ -48,6 +48,7 @@ struct BmGeom {
 // hs[y][d][xv] (d = 0..ndisp-1 candidates in the library's order: disparity = ndisp-1-d+mind; d = ndisp: texture).
 // The two row segments sit in LDS as bytes; a window is summed four taps at a time with v_sad_u8 on words assembled from
 // aligned LDS dwords by v_alignbyte (the byte offset of a lane's window is not a multiple of four).
+#define BM_LWORDS 12      // window words kept in registers (windows up to 47 columns)
 __global__ __launch_bounds__(256) void bm_hsum_kernel(const u8* Lp, const u8* Rp, size_t pitch, BmGeom g, u16* hs)
 {
     extern __shared__ u32 ldsw[];
@@ -78,21 +79,50 @@ __global__ __launch_bounds__(256) void bm_hsum_kernel(const u8* Lp, const u8* Rp
     const int nW = (wsz + 3) >> 2, rem = wsz - 4 * (nW - 1);
     const u32 tailMask = rem == 4 ? 0xFFFFFFFFu : ((1u << (8 * rem)) - 1u);
     const int t = threadIdx.x, wl = t >> 2, shl = t & 3;
-    auto word = [](u32 hi, u32 lo, int sh) -> u32 {          // bytes sh .. sh+3 of the pair (lo, hi)
-        return sh == 0 ? lo : sh == 1 ? __builtin_amdgcn_alignbyte(hi, lo, 1) : sh == 2 ? __builtin_amdgcn_alignbyte(hi, lo, 2)
-                                                                                     : __builtin_amdgcn_alignbyte(hi, lo, 3);
+    auto word = [](u32 hi, u32 lo, int sh) -> u32 {          // bytes sh .. sh+3 of the pair (lo, hi); the shift is a per-lane operand
+        return __builtin_amdgcn_alignbyte(hi, lo, (u32)sh);
     };
-    for (int d = 0; d < g.ndisp; d++) {
-        const int ob = t + d, wr = ob >> 2, shr = ob & 3;   // right column = left column - (ndisp-1-d+mind)
-        u32 lprev = Lw[wl], rprev = Rw[wr], s = 0;
-        for (int k = 0; k < nW; k++) {
-            const u32 lnext = Lw[wl + k + 1], rnext = Rw[wr + k + 1];
-            u32 lv = word(lnext, lprev, shl), rv = word(rnext, rprev, shr);
-            if (k == nW - 1) { lv &= tailMask; rv &= tailMask; }
-            s = __builtin_amdgcn_sad_u8(lv, rv, s);
-            lprev = lnext; rprev = rnext;
+    if (nW <= BM_LWORDS) {
+        // the left window does not depend on the candidate: its words are assembled once and stay in registers
+        u32 lv[BM_LWORDS];
+        {
+            u32 lprev = Lw[wl];
+#pragma unroll
+            for (int k = 0; k < BM_LWORDS; k++) {
+                const u32 lnext = k < nW ? Lw[wl + k + 1] : 0u;
+                lv[k] = k < nW ? word(lnext, lprev, shl) : 0u;
+                if (k == nW - 1) lv[k] &= tailMask;
+                lprev = lnext;
+            }
         }
-        out[(size_t)d * g.Wv] = (u16)s;
+        for (int d = 0; d < g.ndisp; d++) {
+            const int ob = t + d, wr = ob >> 2, shr = ob & 3;   // right column = left column - (ndisp-1-d+mind)
+            u32 rprev = Rw[wr], s = 0;
+#pragma unroll
+            for (int k = 0; k < BM_LWORDS; k++) {
+                if (k < nW) {
+                    const u32 rnext = Rw[wr + k + 1];
+                    u32 rv = word(rnext, rprev, shr);
+                    if (k == nW - 1) rv &= tailMask;
+                    s = __builtin_amdgcn_sad_u8(lv[k], rv, s);
+                    rprev = rnext;
+                }
+            }
+            out[(size_t)d * g.Wv] = (u16)s;
+        }
+    } else {
+        for (int d = 0; d < g.ndisp; d++) {
+            const int ob = t + d, wr = ob >> 2, shr = ob & 3;   // right column = left column - (ndisp-1-d+mind)
+            u32 lprev = Lw[wl], rprev = Rw[wr], s = 0;
+            for (int k = 0; k < nW; k++) {
+                const u32 lnext = Lw[wl + k + 1], rnext = Rw[wr + k + 1];
+                u32 lv = word(lnext, lprev, shl), rv = word(rnext, rprev, shr);
+                if (k == nW - 1) { lv &= tailMask; rv &= tailMask; }
+                s = __builtin_amdgcn_sad_u8(lv, rv, s);
+                lprev = lnext; rprev = rnext;
+            }
+            out[(size_t)d * g.Wv] = (u16)s;
+        }
     }
     u32 lprev = Lw[wl], tx = 0;
     const u32 capw = (u32)g.cap * 0x01010101u;
