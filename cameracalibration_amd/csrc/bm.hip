@@ -43,6 +43,7 @@ struct BmGeom {
     int H, W, ndisp, mind, w, cap;
     int xmin, Wv;            // first valid column and number of valid columns
     int ymin, Hv;            // first valid row and number of valid rows
+    int band;                // output rows per workgroup of the vertical pass
 };
 
 // hs[y][d][xv] (d = 0..ndisp-1 candidates in the library's order: disparity = ndisp-1-d+mind; d = ndisp: texture).
@@ -137,7 +138,6 @@ __global__ __launch_bounds__(256) void bm_hsum_kernel(const u8* Lp, const u8* Rp
 }
 
 constexpr int BM_DPT = 32;      // candidates per thread
-constexpr int BM_BAND = 32;     // output rows per workgroup
 
 struct BmSelect { int textureThreshold, uniquenessRatio; };
 
@@ -156,7 +156,7 @@ __global__ void bm_vsum_wta_kernel(const u16* hs, BmGeom g, BmSelect sel, int16_
     const int xvc = colOk ? xv : g.Wv - 1;
     const int d0 = wv * BM_DPT;
     const int w = g.w, ndisp = g.ndisp;
-    const int yv0 = blockIdx.y * BM_BAND, yv1 = min(yv0 + BM_BAND, g.Hv);
+    const int yv0 = blockIdx.y * g.band, yv1 = min(yv0 + g.band, g.Hv);
     const size_t rowStride = (size_t)(ndisp + 1) * g.Wv;
     // a row's base is uniform and the element offsets are 32-bit (one row of window sums is far below 2^31 elements):
     // no 64-bit address per candidate is kept in registers
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void bm_validate_kernel(int16_t* disp, const i
 
 static bool bm_geom(int H, int W, const mdisp_stereobm_params* p, BmGeom& g)
 {
-    g.H = H; g.W = W; g.ndisp = p->numDisparities; g.mind = p->minDisparity; g.w = p->blockSize / 2; g.cap = p->preFilterCap;
+    g.H = H; g.W = W; g.ndisp = p->numDisparities; g.mind = p->minDisparity; g.w = p->blockSize / 2; g.cap = p->preFilterCap; g.band = 32;
     const int maxD = g.mind + g.ndisp - 1;
     const int lofs = maxD > 0 ? maxD : 0, rofs = maxD < 0 ? -maxD : 0;
     g.xmin = lofs + g.w; g.Wv = W - g.w - g.xmin;
@@ -339,7 +339,20 @@ int md_stereobm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitchIn, i
     const size_t ldsV = (size_t)(3 * 2 * NW * 64 + 2 * 2 * 64) * sizeof(int);
     BmSelect sel{p->textureThreshold, p->uniquenessRatio};
     if (cost) MD_HIP(hipMemsetAsync(cost, 0, n * sizeof(int), s));
-    bm_vsum_wta_kernel<<<dim3((g.Wv + 63) / 64, (g.Hv + BM_BAND - 1) / BM_BAND), NW * 64, ldsV, s>>>(hs, g, sel, dDisp, cost);
+    // Rows per workgroup of the vertical pass: a band first sums the 2w + 1 rows above its first output row, so taller bands
+    // read less, but there must be enough workgroups for the device (16 waves per CU at this kernel's register count).
+    // Measured (1920x1080 x 256, block 21: 16 / 32 / 64 / 128 rows = 1.26 / 0.87 / 0.57 / 1.23 ms; 1280x720 x 144, block 35:
+    // 32 best; 640x480 x 64: 16 best): the tallest of 64, 32, 16 that still gives 0.4 workgroups per place.
+    {
+        int dev = 0, cus = 0;
+        MD_HIP(hipGetDevice(&dev));
+        MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const long places = (long)std::max(cus, 1) * std::max(16 / NW, 1);
+        g.band = 16;
+        for (int b = 64; b > 16; b /= 2)
+            if ((long)((g.Wv + 63) / 64) * ((g.Hv + b - 1) / b) * 10 >= places * 4) { g.band = b; break; }
+    }
+    bm_vsum_wta_kernel<<<dim3((g.Wv + 63) / 64, (g.Hv + g.band - 1) / g.band), NW * 64, ldsV, s>>>(hs, g, sel, dDisp, cost);
     MD_HIP(hipGetLastError());
     if (cost) {
         MD_REQUIRE((size_t)W * 8 <= 64 * 1024, MDISP_E_RANGE, "disp12MaxDiff >= 0 is built for widths up to 8192");

@@ -43,6 +43,17 @@ def test_stereobm_bit_exact(api, orc, case):
         assert (got != filtered).any()          # the case exercises the matcher, not only the frame
 
 
+@pytest.mark.parametrize("size", [(1080, 1920, 256, 21, {}), (720, 1280, 144, 35, {"minDisparity": 20, "disp12MaxDiff": 1})])
+def test_stereobm_large_frames_bit_exact(api, orc, size):
+    """Sizes at which the vertical pass takes its taller bands (64 and 32 output rows per workgroup; the small cases above run with
+    16), and the horizontal pass its register-resident window words with 6 and 9 words per window."""
+    H, W, nd, bs, kw = size
+    L, R, _ = api.synth_pair(0x5EED0061, H, W, kw.get("minDisparity", 0) + nd)
+    got, exp = _run(api, orc, L, R, nd, bs, kw)
+    assert np.array_equal(got, exp)
+    assert (got != (kw.get("minDisparity", 0) - 1) * 16).mean() > 0.02      # the matcher ran, not only the frame
+
+
 def test_stereobm_on_the_bundled_pair(api, orc):
     import os
     from PIL import Image
