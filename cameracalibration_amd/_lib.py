@@ -63,6 +63,7 @@ EXPORTS = [
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
     "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
+    "mdisp_context_device_bytes",
 ]
 
 _lib = None
@@ -143,6 +144,8 @@ def load():
     lib.mdisp_asw_gifs_band_stats_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, par, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
+    lib.mdisp_context_device_bytes.argtypes = [vp]
+    lib.mdisp_context_device_bytes.restype = C.c_size_t
     sbp = P(mdisp_stereobm_params)
     lib.mdisp_stereobm_compute.argtypes = [vp, img, img, sbp, img]
     lib.mdisp_stereobm_workspace_bytes.argtypes = [C.c_int, C.c_int, sbp]

@@ -3,6 +3,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <new>
 
@@ -18,14 +19,17 @@ void mdisp_set_error(const char* fmt, ...)
 
 extern "C" const char* mdisp_last_error(void) { return g_err; }
 
-static int g_tune[MDISP_TUNE_COUNT];
-static const bool g_tune_ready = [] { for (int& v : g_tune) v = -1; return true; }();      // -1: the built-in choice
-int md_tune(int key) { return key >= 0 && key < MDISP_TUNE_COUNT ? g_tune[key] : -1; }
-void md_tune_clear(int key) { if (key >= 0 && key < MDISP_TUNE_COUNT) g_tune[key] = -1; }
+// the scheduling overrides are read by compute paths on any host thread and written by mdisp_tuning_set: atomic words
+static std::atomic<int> g_tune[MDISP_TUNE_COUNT];
+static const bool g_tune_ready = [] { for (auto& v : g_tune) v.store(-1, std::memory_order_relaxed); return true; }();      // -1: the built-in choice
+int md_tune(int key) { return key >= 0 && key < MDISP_TUNE_COUNT ? g_tune[key].load(std::memory_order_relaxed) : -1; }
+void md_tune_clear(int key) { if (key >= 0 && key < MDISP_TUNE_COUNT) g_tune[key].store(-1, std::memory_order_relaxed); }
+// reads a one-shot override and clears it in one step, so two threads cannot both consume it
+int md_tune_take(int key) { return key >= 0 && key < MDISP_TUNE_COUNT ? g_tune[key].exchange(-1, std::memory_order_relaxed) : -1; }
 extern "C" int mdisp_tuning_set(int key, int value)
 {
     MD_REQUIRE(key >= 0 && key < MDISP_TUNE_COUNT, MDISP_E_BADARG, "unknown tuning key %d", key);
-    g_tune[key] = value < 0 ? -1 : value;
+    g_tune[key].store(value < 0 ? -1 : value, std::memory_order_relaxed);
     return MDISP_OK;
 }
 extern "C" int mdisp_tuning_get(int key) { return md_tune(key); }
@@ -89,10 +93,9 @@ static int create_ctx(mdisp_ctx** out, int device, void* stream, bool useGiven)
     if (hipMalloc((void**)&c->sgm_err, 256) != hipSuccess || hipMemset(c->sgm_err, 0, 256) != hipSuccess) {
         mdisp_set_error("hipMalloc of the context's status word failed"); delete c; return MDISP_E_NOMEM;
     }
-    {
-        const int rc = scratch_of_device(device, &c->noalloc_scratch);
-        if (rc) { (void)hipFree(c->sgm_err); delete c; return rc; }
-    }
+    // the no-allocation entry point's scratch address: resolved here when possible (hipGetSymbolAddress allocates nothing);
+    // a failure only disables that one entry point, which then tries again and reports the error itself
+    if (scratch_of_device(device, &c->noalloc_scratch) != MDISP_OK) c->noalloc_scratch = nullptr;
     *out = c;
     return MDISP_OK;
 }
@@ -212,6 +215,8 @@ void* mdisp_ws(mdisp_ctx* c, size_t bytes)
     c->ws_bytes = want;
     return c->ws;
 }
+
+extern "C" size_t mdisp_context_device_bytes(mdisp_ctx* c) { return c ? c->ws_bytes + c->stage_bytes : 0; }
 
 extern "C" int mdisp_enable_timing(mdisp_ctx* c, int on)
 {
@@ -517,6 +522,7 @@ extern "C" int mdisp_census_stereo_dev_noalloc(mdisp_ctx* c, const uint8_t* d_le
                "%dx%d with maxDisparity %d needs %zu bytes of scratch, the fixed array holds %u", cols, rows, p->maxDisparity, cv.off,
                (unsigned)MDISP_NOALLOC_SCRATCH_BYTES);
     MD_HIP(hipSetDevice(c->device));
+    if (!c->noalloc_scratch) MD_TRY(scratch_of_device(c->device, &c->noalloc_scratch));
     u8* base = c->noalloc_scratch;     // the device address of `scratch` on the context's GPU, never the symbol itself
     const u8* ref = p->isDispLeft ? d_left : d_right;
     const u8* other = p->isDispLeft ? d_right : d_left;

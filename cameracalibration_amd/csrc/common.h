@@ -15,6 +15,7 @@ void mdisp_set_error(const char* fmt, ...);
 // process-wide scheduling override (mdisp_tuning_set): the value, or -1 when the default applies
 int md_tune(int key);
 void md_tune_clear(int key);
+int md_tune_take(int key);      // value of a one-shot override, cleared by the same atomic exchange
 
 #define MD_HIP(call)                                                                      \
     do {                                                                                  \

@@ -145,26 +145,36 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
 {
     // Per plane and pixel of image row y one dword: the value u, and the minimum u0 and maximum u1 of u and its two
     // half-way neighbours (u + u(x-1)) / 2, (u + u(x+1)) / 2 -- at the image edge the pixel itself, as the library defines
-    // them.  [2 * np][TS]: left planes, then right planes, for the TS = BT_SEG + 256 + bs columns from `lo` on that this
-    // workgroup's segment and candidates can reach.  A pixel cost is then two table reads per plane (the left one the same
-    // for every lane) and a dozen integer operations, whatever the candidate.
+    // them.  Two tables with their own origins: the left planes [np][TSL] hold the columns [xl0, xl1] of the segment's
+    // windows (at most BT_SEG + bs - 1 of them), the right planes [np][TSR] the columns those reach through this
+    // workgroup's 256 candidates, [xl0 - minD - kHi, xl1 - minD - kLo] clipped to the image (at most 255 more), so
+    // neither extent depends on minDisparity or on which block of candidates the workgroup owns.  A pixel cost is then
+    // two table reads per plane (the left one the same for every lane) and a dozen integer operations.
     extern __shared__ u32 btTable[];
     const int cn = CN ? CN : g.cn, np = 2 * cn, W = g.W, y = blockIdx.y;
     const int h = g.bs / 2, W1 = g.W1;
     const int xa = blockIdx.z * BT_SEG, xb = min(xa + BT_SEG, W1);
-    const int k = blockIdx.x * 256 + threadIdx.x, TS = BT_SEG + 256 + g.bs;
-    int tlo;
+    const int k = blockIdx.x * 256 + threadIdx.x, TSL = BT_SEG + g.bs, TSR = BT_SEG + g.bs + 255;
+    u32* const tabL = btTable;
+    u32* const tabR = btTable + np * TSL;
+    int llo, rlo;
     {
-        const int kHi = min(blockIdx.x * 256 + 255, g.D - 1);
+        const int kLo = blockIdx.x * 256, kHi = min(kLo + 255, g.D - 1);
         const int xl0 = max(xa - h, 0) + g.minX1, xl1 = min(xb - 1 + h, W1 - 1) + g.minX1;      // left columns of the segment's windows
-        const int lo = max(min(xl0, xl0 - (g.minD + kHi)), 0), hi = min(max(xl1, xl1 - (g.minD + (int)blockIdx.x * 256)), W - 1);
-        const int n = hi - lo + 1;
-        tlo = lo;
-        for (int i = threadIdx.x; i < 2 * np * n; i += 256) {
-            const int c = i / n, x = lo + i - c * n;
-            const u8* row = (c < np ? p1 + (size_t)c * g.N : p2 + (size_t)(c - np) * g.N) + (size_t)y * W;
+        const int r0 = max(xl0 - (g.minD + kHi), 0), r1 = min(xl1 - (g.minD + kLo), W - 1);
+        const int nl = xl1 - xl0 + 1, nr = r1 - r0 + 1;
+        llo = xl0; rlo = r0;
+        auto entry = [&](const u8* row, int x) -> u32 {
             const int u = row[x], ul = (u + row[max(x - 1, 0)]) / 2, ur = (u + row[min(x + 1, W - 1)]) / 2;
-            btTable[c * TS + x - lo] = (u32)u | ((u32)min(min(ul, ur), u) << 8) | ((u32)max(max(ul, ur), u) << 16);
+            return (u32)u | ((u32)min(min(ul, ur), u) << 8) | ((u32)max(max(ul, ur), u) << 16);
+        };
+        for (int i = threadIdx.x; i < np * nl; i += 256) {
+            const int c = i / nl, x = xl0 + i - c * nl;
+            tabL[c * TSL + x - xl0] = entry(p1 + (size_t)c * g.N + (size_t)y * W, x);
+        }
+        for (int i = threadIdx.x; i < np * nr; i += 256) {
+            const int c = i / nr, x = r0 + i - c * nr;
+            tabR[c * TSR + x - r0] = entry(p2 + (size_t)c * g.N + (size_t)y * W, x);
         }
     }
     __syncthreads();
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
         int cost = 0;
 #pragma unroll
         for (int c = 0; c < np; c++) {
-            const u32 l = btTable[c * TS + x - tlo], r = btTable[(np + c) * TS + x2 - tlo];
+            const u32 l = tabL[c * TSL + x - llo], r = tabR[c * TSR + x2 - rlo];
             const int u = l & 0xFF, u0 = (l >> 8) & 0xFF, u1 = (l >> 16) & 0xFF;
             const int v = r & 0xFF, v0 = (r >> 8) & 0xFF, v1 = (r >> 16) & 0xFF;
             const int c0 = max(max(0, u - v1), v0 - u);
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256) void bt_cost_hsum_kernel(const u8* __restrict_
     // the row is cut into segments of BT_SEG columns (blockIdx.z), each starting from a freshly summed window.
     // Every pixel cost is evaluated once: a lane keeps the costs of the window's columns in its own ring of bs + 1
     // slots in LDS ([slot][lane], conflict-free), so the column that leaves the window is read back, not recomputed.
-    int16_t* ring = reinterpret_cast<int16_t*>(btTable + 2 * np * TS) + threadIdx.x;
+    int16_t* ring = reinterpret_cast<int16_t*>(btTable + np * (TSL + TSR)) + threadIdx.x;
     const int R = g.bs + 1;
     int slotLeave = (xa - h) % R;
     if (slotLeave < 0) slotLeave += R;
@@ -758,7 +768,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
     // plane rows + the per-lane ring of pixel costs (bs + 1 slots of 256 int16)
-    const size_t rowLds = (size_t)4 * cn * (BT_SEG + 256 + g.bs) * sizeof(u32) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
+    const size_t rowLds = (size_t)2 * cn * ((BT_SEG + g.bs) + (BT_SEG + g.bs + 255)) * sizeof(u32) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
     if (rowLds <= 60 * 1024) {
         const dim3 gh((g.D + 255) / 256, H, (g.W1 + BT_SEG - 1) / BT_SEG);
         if (cn == 1) bt_cost_hsum_kernel<1><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);

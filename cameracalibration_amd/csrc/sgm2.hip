@@ -1164,8 +1164,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         int* sync = (int*)afterRec;
         MD_HIP(hipMemsetAsync(sync, 0, l.syncBytes, s));
         if (usedErrWord) *usedErrWord = true;
-        if (md_tune(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
-            md_tune_clear(MDISP_TUNE_SGM_PLANT_ERROR);
+        if (md_tune_take(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
             MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
         }
         const bool s4b = !naturalOut && 4 * (8 * pl.costWin * pl.costWin + pl.P2) <= 255;
@@ -1221,8 +1220,7 @@ int md_sgm2_aggregate(hipStream_t s, const md_sgm_plan& pl, const u8* cL, size_t
         // stream stays visible until the host reads it
         sa.err = errWord;
         if (usedErrWord) *usedErrWord = true;
-        if (md_tune(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
-            md_tune_clear(MDISP_TUNE_SGM_PLANT_ERROR);
+        if (md_tune_take(MDISP_TUNE_SGM_PLANT_ERROR) > 0) {
             MD_HIP(hipMemsetAsync(errWord, 1, sizeof(int), s));
         }
         if (nt == 512) {

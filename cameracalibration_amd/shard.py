@@ -100,6 +100,14 @@ def sgm_row_ranges(rows, band_rows, world):
     return out
 
 
+def check_row_ranges(ranges):
+    """Raises ValueError when any participant's row range is empty (more participants than row bands).  The ranges are
+    the same on every rank, so the error is raised everywhere at once instead of leaving some ranks blocked in a receive."""
+    empty = [r for r, (b, e) in enumerate(ranges) if b >= e]
+    if empty:
+        raise ValueError("more participants than row bands: rank(s) %s would have no rows" % ", ".join(map(str, empty)))
+
+
 def sgm_sweep_plan(rank, world):
     """The two sweeps of participant `rank`, in the order it runs them: [(direction, second, source, destination)].
     The downward wave-front (direction 0) starts at rank 0 and reaches rank r after r hops, the upward one (direction 1)
@@ -202,7 +210,11 @@ class RowShardedSGBM:
         band, bnd, ws = C.c_int(), C.c_size_t(), C.c_size_t()
         _lib.check(self.lib.mdisp_sgbm_rows_geometry(rows, cols, C.byref(params), C.byref(band), C.byref(bnd), C.byref(ws)))
         self.band_rows, self.boundary_bytes, self.ws_bytes = band.value, bnd.value, ws.value
-        self.begin, self.end = sgm_row_ranges(rows, band.value, world)[rank]
+        ranges = sgm_row_ranges(rows, band.value, world)
+        # every rank computes the same ranges, so every rank raises together: raising only on the empty ranks would
+        # leave their neighbours waiting for boundary states that never come
+        check_row_ranges(ranges)
+        self.begin, self.end = ranges[rank]
         self.ws = torch.empty(ws.value, dtype=torch.uint8, device=device)
         self.bnd_in = torch.empty(bnd.value, dtype=torch.uint8, device=device)
         self.bnd_out = [torch.empty(bnd.value, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -224,8 +236,6 @@ class RowShardedSGBM:
         """Both sweeps with the boundary exchange in between; `exchange` has send(tensor, dst, tag), recv(tensor, src,
         tag) and wait().  Synchronises the context's stream (a hand-off timeout raises here)."""
         import torch
-        if self.begin >= self.end:
-            raise ValueError("more participants than row bands: this rank has no rows")
         run_sweep_plan(self.rank, self.world, lambda step, bnd: self.sweep(step, d_left, d_right, pitch, d_disp, bnd), exchange, self.bnd_in,
                        before_sweep=torch.cuda.synchronize,      # the receive ran on torch's stream, the sweep runs on the context's
                        after_sweep=self.ctx.synchronize)

@@ -157,6 +157,9 @@ int  mdisp_create(mdisp_ctx** ctx, int device, void* stream);
 int  mdisp_create_on_stream(mdisp_ctx** ctx, int device, void* stream);
 void mdisp_destroy(mdisp_ctx* ctx);
 int  mdisp_synchronize(mdisp_ctx* ctx);
+/* Bytes of device memory the context has allocated so far for its grow-only workspace and copy staging (0 for a fresh
+ * context).  Diagnostic, no counterpart in the reference: lets a caller verify that a call allocated nothing. */
+size_t mdisp_context_device_bytes(mdisp_ctx* ctx);
 
 /* ---- census family: countCensusImg*, methods_disp.cpp:415-714 ----
  * dst is CV_8U of src's size.  `arg` is the radius for CIRCLE and the window for the

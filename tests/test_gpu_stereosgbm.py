@@ -36,6 +36,11 @@ CASES = [
     (40, 120, 1, (0, 32, 5, 20, 100, 1, 31, 130, 0, 0, 0)),                # 100 - uniquenessRatio negative
     (24, 340, 1, (0, 272, 5, 30, 200, 1, 31, 10, 0, 0, 1)),                # more than 256 disparities: eight per lane
     (24, 340, 1, (0, 272, 5, 30, 200, 1, 31, 10, 0, 0, 0)),
+    # wide frames where the columns the right planes' table must hold do not start where the left planes' do:
+    # minDisparity > 0 with 256 candidates, and the second block of 256 candidates of a 512-candidate range
+    (12, 1920, 1, (16, 256, 7, 490, 1960, 1, 63, 10, 0, 0, 0)),
+    (10, 1100, 1, (0, 512, 5, 30, 200, 1, 31, 10, 0, 0, 0)),
+    (10, 1100, 3, (5, 512, 9, 30, 200, 1, 31, 10, 0, 0, 1)),
 ]
 
 

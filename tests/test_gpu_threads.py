@@ -42,3 +42,42 @@ def test_left_and_right_routines_run_concurrently(api):
         for i in range(2):
             for a, b in zip(out[i], seq[i]):
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(200, 320, 64, 12), (1080, 1920, 256, 8)])
+def test_two_contexts_run_batched_row_bands_concurrently(api, shape):
+    """Two contexts, two host threads, each a batch large enough for the one-launch row-band schedule (whose workgroups
+    wait on tickets and progress words inside the launch): the two launches share the device, neither may starve the
+    other, the results equal the sequential ones and the contexts' sticky error words stay clear."""
+    from cameracalibration_amd import _lib
+    # the second shape is the benchmark's frame: 8 pairs x 68 bands x 2 directions = 1088 workgroups per launch, more than
+    # the device holds at once, so the two launches compete for residency
+    H, W, D, n = shape
+    sp = api.sgbm_params(0, D, 8, 32, 10, 1, 8, 1)
+    sets = []
+    for k in range(2):
+        pairs = [api.synth_pair(0x5EED0101 + 100 * k + 2 * i, H, W, D)[:2] for i in range(n)]
+        sets.append(([a for a, _ in pairs], [b for _, b in pairs]))
+    seq = [api.sgbm_compute_batch(ls, rs, sp, chunk=n) for ls, rs in sets]
+    for _ in range(3):
+        ctxs = [_lib.Context(), _lib.Context()]
+        out, err = [None, None], []
+
+        def run(i):
+            try:
+                out[i] = api.sgbm_compute_batch(sets[i][0], sets[i][1], sp, chunk=n, ctx=ctxs[i])
+                ctxs[i].synchronize()           # raises if a band of this context's launches timed out waiting
+            except Exception as e:          # noqa: BLE001
+                err.append(e)
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=100)
+        assert not any(t.is_alive() for t in ts), "a batched call did not return"
+        assert not err, err
+        for i in range(2):
+            assert np.array_equal(out[i], seq[i])
+        for c in ctxs:
+            c.close()

@@ -166,6 +166,16 @@ def test_sgm_row_ranges_are_whole_bands_that_tile_the_image():
                 assert all(b == e or (b % band == 0 and (e % band == 0 or e == rows)) for b, e in edges)      # ranks beyond the last band: empty
 
 
+def test_more_participants_than_bands_is_an_error_on_every_rank():
+    """An empty row range is refused from the ranges alone (identical on every rank), so all ranks raise together and
+    nobody is left waiting for a neighbour's boundary states."""
+    ranges = shard.sgm_row_ranges(40, 16, 8)          # 3 bands, 8 participants
+    assert any(b >= e for b, e in ranges)
+    with pytest.raises(ValueError):
+        shard.check_row_ranges(ranges)
+    shard.check_row_ranges(shard.sgm_row_ranges(40, 16, 3))
+
+
 def test_sgm_sweep_plan_dependencies():
     for world in (1, 2, 3, 4, 8):
         plans = [shard.sgm_sweep_plan(r, world) for r in range(world)]

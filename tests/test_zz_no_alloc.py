@@ -30,13 +30,19 @@ def test_no_alloc_entry_point_matches_the_allocating_one(api, orc):
         (60, 88, 16, 9, 0, 15, True, api.STATISTIC_MULTISCALE_CENSUS, api.AGG_NONE),   # uses the zero-initialised histogram
         (480, 640, 64, 7, 0, 63, True, api.BASIC_CENSUS, api.AGG_BOX),
     ]
+    # a context of its own for the no-allocation calls: it must never acquire device memory
+    bare = _lib.Context()
+    assert lib.mdisp_context_device_bytes(bare.handle) == 0
     for (H, W, nd, win, minD, maxD, left, method, agg) in cases:
         L, R, _ = api.synth_pair(0x5EED0001 + H, H, W, nd)
-        got = _run(lib, _lib, ctx, lib.mdisp_census_stereo_dev_noalloc, L, R, win, minD, maxD, left, method, agg)
+        got = _run(lib, _lib, bare, lib.mdisp_census_stereo_dev_noalloc, L, R, win, minD, maxD, left, method, agg)
+        assert lib.mdisp_context_device_bytes(bare.handle) == 0, "the no-allocation entry point grew the context's workspace"
         ref = _run(lib, _lib, ctx, lib.mdisp_census_stereo_dev, L, R, win, minD, maxD, left, method, agg)
         assert np.array_equal(got, ref)
         if method == api.BASIC_CENSUS:
             assert np.array_equal(got, orc.census_stereo(L, R, win, minD, maxD, left, orc.BASIC_CENSUS, orc.AGG_BOX))
+    assert lib.mdisp_context_device_bytes(ctx.handle) > 0      # the allocating entry point did use the workspace
+    bare.close()
     ctx.close()
 
 
