@@ -20,7 +20,7 @@ E_BADARG, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_RANGE, E_NOMEM = -1, -2, -3, -4, -
 # keys of mdisp_tuning_set (include/mdisp.h)
 (TUNE_SGM_SPLIT_MAX, TUNE_SGM_PATH_WAVES_MAX, TUNE_SGM_STRIP_LANES, TUNE_SGM_FORCE_PREPASS, TUNE_SGM_LANES16,
  TUNE_SGM_PER_DIRECTION, TUNE_SGBM_BT_SEQUENTIAL, TUNE_SGM_PIPELINE, TUNE_SGM_PLANT_ERROR, TUNE_SGM_BAND_SLACK, TUNE_SGM_PAIR_GROUP,
- TUNE_SGM_HAND_RING, TUNE_SGM_MEET_MAX, TUNE_SGM_ONE_LAUNCH, TUNE_COUNT) = range(15)
+ TUNE_SGM_HAND_RING, TUNE_SGM_MEET_MAX, TUNE_SGM_ONE_LAUNCH, TUNE_SAT_INT_TABLES, TUNE_COUNT) = range(16)
 
 
 class mdisp_image(C.Structure):
@@ -63,7 +63,7 @@ EXPORTS = [
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
     "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
-    "mdisp_context_device_bytes",
+    "mdisp_context_device_bytes", "mdisp_sad_inte_mode",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def load():
     lib.mdisp_hamming_dist.argtypes = [vp, img, img, img]
     lib.mdisp_census_stereo.argtypes = [vp, img, img, par, C.c_int, C.c_int, img]
     lib.mdisp_sad_inte.argtypes = [vp, img, img, par, img]
+    lib.mdisp_sad_inte_mode.argtypes = [vp, img, img, par, C.c_int, img]
     lib.mdisp_sad_box.argtypes = [vp, img, img, par, img]
     lib.mdisp_guided_filter.argtypes = [vp, img, img, C.c_int, C.c_double, C.c_int, img, C.c_int, C.c_double, img, img]
     lib.mdisp_steer_filter.argtypes = [vp, img, img]

@@ -71,9 +71,15 @@ def _pair_call(fn, param, out_dtype, ctx, *extra):
     return out
 
 
-def computeSAD_inteOpti(param, ctx=None):
-    """methods_disp.h:43 -> CV_8U disparity."""
-    return _pair_call(load().mdisp_sad_inte, param, np.uint8, ctx)
+SAT_F32, SAT_INT = 0, 1
+
+
+def computeSAD_inteOpti(param, ctx=None, tables=None):
+    """methods_disp.h:43 -> CV_8U disparity.  tables: None = the library's default (the reference's CV_32F integral tables),
+    SAT_F32 or SAT_INT (exact integer tables) per call."""
+    if tables is None:
+        return _pair_call(load().mdisp_sad_inte, param, np.uint8, ctx)
+    return _pair_call(load().mdisp_sad_inte_mode, param, np.uint8, ctx, int(tables))
 
 
 def computeSAD_BFOpti(param, ctx=None):

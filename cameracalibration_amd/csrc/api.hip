@@ -413,7 +413,7 @@ static int stage_pair(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     size_t o_I = 0, o_best = 0;
     if (need_sat) {
         const int nt = md_sad_inte_tables(H, W, p->maxDisparity - p->minDisparity + 1);
-        o_I = cv.take((size_t)nt * (H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 4);
+        o_I = cv.take((size_t)nt * (H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 8);
     }
     size_t o_extra = cv.take(extra_bytes);
     u8* base = (u8*)mdisp_ws(c, cv.off);
@@ -530,7 +530,8 @@ extern "C" int mdisp_census_stereo_dev_noalloc(mdisp_ctx* c, const uint8_t* d_le
                               base + o_cr, pitchP, base + o_cp, base + o_scr, d_disp, nullptr);
 }
 
-static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out, bool inte)
+static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out, bool inte,
+                      int tableMode = MDISP_SAT_F32)
 {
     MD_REQUIRE(c, MDISP_E_BADARG, "null context");
     int rc;
@@ -547,7 +548,7 @@ static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
     if (rc) return rc;
     const int off0 = p->isDispLeft ? (maxD - minD) : minD, offStep = p->isDispLeft ? -1 : 1;
     if (inte) rc = md_sad_inte(s, b.ref, b.pitchW, b.pad, b.pitchP, H, W, minD, maxD, off0, offStep, p->winSize,
-                               (u8*)b.out, opitch, b.I, b.best);
+                               tableMode == MDISP_SAT_F32, (u8*)b.out, opitch, b.I, b.best);
     else rc = md_cost_box_wta(s, b.ref, b.pitchW, b.pad, b.pitchP, H, W, minD, maxD, off0, offStep, p->winSize,
                               MD_COST_ABSDIFF_SQR, MD_OUT_U8, b.out, opitch);
     if (rc) return rc;
@@ -557,7 +558,14 @@ static int sad_common(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, 
 }
 
 extern "C" int mdisp_sad_inte(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out)
-{ return sad_common(c, L, R, p, out, true); }
+{ return sad_common(c, L, R, p, out, true, md_tune(MDISP_TUNE_SAT_INT_TABLES) > 0 ? MDISP_SAT_INT : MDISP_SAT_F32); }
+
+extern "C" int mdisp_sad_inte_mode(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, int table_mode,
+                                   mdisp_image* out)
+{
+    MD_REQUIRE(table_mode == MDISP_SAT_F32 || table_mode == MDISP_SAT_INT, MDISP_E_BADARG, "unknown table mode %d", table_mode);
+    return sad_common(c, L, R, p, out, true, table_mode);
+}
 
 extern "C" int mdisp_sad_box(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out)
 { return sad_common(c, L, R, p, out, false); }
@@ -819,11 +827,15 @@ extern "C" int mdisp_legacy_disparity(mdisp_ctx* c, const mdisp_image* L, const 
     const size_t pitch = md_align(W, 256), p3 = md_align((size_t)W * 3, 256);
     Carver cv;
     size_t o_l = cv.take(pitch * H), o_r = cv.take(pitch * H), o_st = cv.take(p3 * H), o_d = cv.take(pitch * H);
+    size_t o_I = 0, o_best = 0;
+    const bool tables = md_legacy_uses_tables(method) && numD > 0;
+    if (tables) { o_I = cv.take((size_t)md_sad_inte_tables(H, W, numD) * (H + 1) * (W + 1) * 4); o_best = cv.take((size_t)H * W * 8); }
     u8* base = (u8*)mdisp_ws(c, cv.off);
     if (!base) return MDISP_E_NOMEM;
     if ((rc = upload_gray(c, L, base + o_l, pitch, base + o_st, p3))) return rc;
     if ((rc = upload_gray(c, R, base + o_r, pitch, base + o_st, p3))) return rc;
-    if ((rc = md_legacy_disparity(c->stream, base + o_l, pitch, base + o_r, pitch, H, W, method, winSize, T, minD, numD, base + o_d, pitch)))
+    if ((rc = md_legacy_disparity(c->stream, base + o_l, pitch, base + o_r, pitch, H, W, method, winSize, T, minD, numD, base + o_d, pitch,
+                                  tables ? (int*)(base + o_I) : nullptr, tables ? (int*)(base + o_best) : nullptr)))
         return rc;
     MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, pitch, W, H));
     MD_HIP(hipStreamSynchronize(c->stream));

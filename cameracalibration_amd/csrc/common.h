@@ -150,16 +150,21 @@ int md_fgs_convert(hipStream_t s, const int16_t* src, float* dst, size_t n);
 int md_fgs_convert_back(hipStream_t s, const float* src, int16_t* dst, size_t n);
 
 // legacy.hip: fixed-window matchers of namespace stereomatch_1
+// I / best: the integral-table scratch of md_sad_inte (used by the _inteOpti kinds only, may be null otherwise)
 int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, size_t rp, int H, int W, int method, int winSize,
-                        int T, int minD, int numD, u8* dOut, size_t op);
+                        int T, int minD, int numD, u8* dOut, size_t op, int* I, int* best);
+bool md_legacy_uses_tables(int method);
 
 // stereo.hip
 int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
                     int minD, int maxD, int off0, int offStep, int win, int costKind, int outKind, void* out, size_t op);
-// I: md_sad_inte_tables() tables of (H+1)*(W+1) ints, best: H*W ints of device scratch
+// I: md_sad_inte_tables() tables of (H+1)*(W+1) words, best: 2*H*W words of device scratch.  floatTables: the reference's
+// CV_32F table arithmetic (rounds above 2^24), else exact 32-bit integer tables.
 int md_sad_inte_tables(int H, int W, int D);
 int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
-                int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best);
+                int minD, int maxD, int off0, int offStep, int win, int floatTables, u8* out, size_t op, int* I, int* best);
+int md_legacy_inte(hipStream_t s, const u8* L, size_t lp, const u8* R, size_t rp, int H, int W, int minD, int numD, int win,
+                   int square, int clampT, int T, int floatTables, u8* out, size_t op, int* I, int* best);
 int md_lr_check(hipStream_t s, const float* dL, const float* dR, int H, int W, float thresh, u8* vL, u8* vR);
 int md_remap(hipStream_t s, const u8* src, size_t sp, int sH, int sW, int cn, const int16_t* m1, const u16* m2,
              int dH, int dW, u8* dst, size_t dp);

@@ -1,6 +1,7 @@
 // The fixed-window matchers of namespace stereomatch_1 (cameraCalibration/methods/method_StereoMatching.cpp:32-869):
 // computeAD / TAD / SD, computeSAD / STAD / SSD and their _inteOpti / _BFOpti variants.  Left / right CV_8UC1,
-// numDisparity is a count, output CV_8U = (char)(16 * winning index).  All sums are exact integers.
+// numDisparity is a count, output CV_8U = (char)(16 * winning index).  Sums are exact integers, except the _inteOpti
+// kinds, which by default go through float summed-area tables in the reference's arithmetic (md_legacy_inte, stereo.hip).
 #include "common.h"
 
 namespace {
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void legacy_pixel_kernel(LegacyArgs a)
 // Window variants.  A workgroup owns a 32 x 8 tile; per candidate the difference image of the tile and
 // its halo goes to LDS, is summed along rows, then along columns.
 //   foot 0 (:83-141 and twins): full window; a candidate whose centre column i - d lies left of h keeps cost 0
-//   foot 1 (_inteOpti): differences are 0 left of column d; the integral-image lookup covers rows j-h .. j+h-1
-//          and columns i-h .. i+h-1
+//   foot 1 (_inteOpti with exact sums, MDISP_TUNE_SAT_INT_TABLES): differences are 0 left of column d; the
+//          integral-image lookup covers rows j-h .. j+h-1 and columns i-h .. i+h-1
 //   foot 2 (_BFOpti): the same difference image, squared by sqrBoxFilter, full window, BORDER_REFLECT_101
 #define LG_X 32
 #define LG_Y 8
@@ -98,8 +99,14 @@ __global__ __launch_bounds__(256) void legacy_window_kernel(LegacyArgs a)
 
 }  // namespace
 
+bool md_legacy_uses_tables(int method)
+{
+    return (method == MDISP_LEGACY_SAD_INTE || method == MDISP_LEGACY_STAD_INTE || method == MDISP_LEGACY_SSD_INTE) &&
+           md_tune(MDISP_TUNE_SAT_INT_TABLES) <= 0;
+}
+
 int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, size_t rp, int H, int W, int method, int winSize,
-                        int T, int minD, int numD, u8* dOut, size_t op)
+                        int T, int minD, int numD, u8* dOut, size_t op, int* I, int* best)
 {
     MD_REQUIRE(method >= MDISP_LEGACY_AD && method <= MDISP_LEGACY_SSD_BF, MDISP_E_BADARG, "unknown matcher %d", method);
     MD_REQUIRE(numD > 0 && minD >= 0, MDISP_E_BADARG, "bad disparity range");
@@ -122,6 +129,11 @@ int md_legacy_disparity(hipStream_t s, const u8* dL, size_t lp, const u8* dR, si
         MD_REQUIRE(winSize <= 63, MDISP_E_UNSUPPORTED, "window above 63 is not supported");
         if (inte || bf) MD_REQUIRE(minD + numD - 1 < W, MDISP_E_BADARG, "disparity range wider than the image");
         a.h = winSize / 2;
+        if (md_legacy_uses_tables(method)) {
+            // the reference's CV_32F integral tables: the winner follows their rounding once entries pass 2^24
+            MD_REQUIRE(I && best, MDISP_E_BADARG, "the integral-image matchers need table scratch");
+            return md_legacy_inte(s, dL, lp, dR, rp, H, W, minD, numD, winSize, a.square, a.clampT, T, 1, dOut, op, I, best);
+        }
         const size_t lds = ((size_t)(LG_X + 2 * a.h) * (LG_Y + 2 * a.h) + (size_t)(LG_Y + 2 * a.h) * LG_X) * sizeof(int);
         legacy_window_kernel<<<dim3((W + LG_X - 1) / LG_X, (H + LG_Y - 1) / LG_Y), 256, lds, s>>>(a);
     }

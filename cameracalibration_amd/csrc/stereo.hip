@@ -330,33 +330,56 @@ int md_cost_box_wta(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size
 }
 
 // ---------------------------------------------------------------------------------------------
-// Integral-image SAD (computeSAD_inteOpti, methods_disp.cpp:207-309) with exact integer tables.
-// Footprint and zero-outside rule are the reference's: cost = I(x+h,y+h) - I(x+h,y-h) - I(x-h,y+h)
-// + I(x-h,y-h) on the (H+1)x(W+1) table, any corner whose index falls outside the table reads 0
-// (getMatVal, :159-171) -- so the window is 2h x 2h and the last h columns/rows produce the
-// reference's negative "garbage" costs, reproduced here exactly.
+// Integral-image SAD (computeSAD_inteOpti, methods_disp.cpp:207-309; stereomatch_1::computeSAD / STAD / SSD_inteOpti,
+// methods/method_StereoMatching.cpp:155-221, 437-504, 722-789).  Per candidate: a difference image, its summed-area
+// table integral(..., CV_32F), cost = I(x+h,y+h) - I(x+h,y-h) - I(x-h,y+h) + I(x-h,y-h) on the (H+1)x(W+1) table, first
+// minimum.  The window is therefore 2h x 2h; in methods_disp.cpp any corner whose index falls outside the table reads 0
+// (getMatVal, :159-171), so the last h columns / rows produce negative "garbage" costs, reproduced here exactly.
+//
+// Two table arithmetics.  FLOAT (the reference's): the library fills a CV_32F table as `s += src[x]` per row (float) and
+// sum[y+1][x+1] = sum[y][x+1] + s, and the four corners combine left to right in float -- above 2^24 (a 255-valued
+// difference image passes it after 65 793 pixels) the entries round, and the winner follows the rounding.  The row sum s
+// stays below 255 * W < 2^24, so it is an exact integer and is formed as an integer prefix sum; the rounding happens in
+// the serial walk down each column, which runs one lane per column (slices side by side).  INT: exact 32-bit tables
+// with the same footprint and zero-outside rule; equal to FLOAT while every table entry stays below 2^24.
 
-// Slices are processed in batches of `nb` tables (grid z / y = slice) so that the serial column
+struct SatSlices {
+    const u8* ref; size_t rp;      // the view the map is computed for
+    const u8* oth; size_t op;      // kind 0: the other view padded by maxDisparity (REFLECT); kind 1: the other view itself
+    int W, kind, off0, offStep;    // kind 0: slice k compares ref(x) with oth(off0 + k * offStep + x)
+    int minD, square;              // kind 1: slice k compares ref(x) with oth(x - minD - k), 0 where x < minD + k; square: min(v^2, 255)
+};
+
+__device__ __forceinline__ int sat_diff(const SatSlices& g, const u8* r, const u8* o, int x, int d)
+{
+    if (g.kind == 0) { const int a = r[x], b = o[x]; return a > b ? a - b : b - a; }
+    if (x < d) return 0;
+    const int a = r[x], b = o[x - d];
+    int v = a > b ? a - b : b - a;
+    if (g.square) v = min(v * v, 255);
+    return v;
+}
+
+// Slices are processed in batches of `nb` tables (grid y = slice) so that the serial column
 // scan of one slice overlaps with those of the others.
 
-// exclusive row prefix of |ref - pad(x+off)|: P[y][x] = sum_{x' < x} diff, x in [0, W]
-__global__ __launch_bounds__(256) void sad_row_prefix_kernel(const u8* __restrict__ ref, size_t rp, const u8* __restrict__ pad,
-                                                             size_t pp, int W, int off0, int offStep, int* __restrict__ Pbase,
-                                                             int PW, size_t tableStride)
+// exclusive row prefix of the difference image: P[y][x] = sum_{x' < x} diff, x in [0, W]
+__global__ __launch_bounds__(256) void sad_row_prefix_kernel(SatSlices g, int k0, int* __restrict__ Pbase, int PW, size_t tableStride)
 {
     __shared__ int part[256];
-    const int y = blockIdx.x, tid = threadIdx.x, k = blockIdx.y;
+    const int y = blockIdx.x, tid = threadIdx.x, k = blockIdx.y, W = g.W;
     const int chunk = (W + 255) / 256;
     const int xb = tid * chunk, xe = min(W, xb + chunk);
-    const u8* r = ref + (size_t)y * rp;
-    const u8* p = pad + (size_t)y * pp + off0 + k * offStep;
+    const u8* r = g.ref + (size_t)y * g.rp;
+    const u8* o = g.oth + (size_t)y * g.op + (g.kind == 0 ? g.off0 + (k0 + k) * g.offStep : 0);
+    const int d = g.minD + k0 + k;
     int* P = Pbase + (size_t)k * tableStride;
     int s = 0;
-    for (int x = xb; x < xe; x++) { int a = r[x], b = p[x]; s += a > b ? a - b : b - a; }
+    for (int x = xb; x < xe; x++) s += sat_diff(g, r, o, x, d);
     part[tid] = s;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int v = tid >= o ? part[tid - o] : 0;
+    for (int o2 = 1; o2 < 256; o2 <<= 1) {
+        int v = tid >= o2 ? part[tid - o2] : 0;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
@@ -365,51 +388,78 @@ __global__ __launch_bounds__(256) void sad_row_prefix_kernel(const u8* __restric
     int* row = P + (size_t)y * PW;
     for (int x = xb; x < xe; x++) {
         row[x] = run;
-        int a = r[x], b = p[x];
-        run += a > b ? a - b : b - a;
+        run += sat_diff(g, r, o, x, d);
     }
     if (xe == W && xb < W) row[W] = run;
     if (W == 0 && tid == 0) row[0] = 0;
 }
 
-// in-place column prefix: I[y+1][x] = sum_{y' <= y} P[y'][x]; row 0 of I is zero.  I has H+1 rows.
+// in-place column prefix: I[y+1][x] = I[y][x] + P[y][x], in T's arithmetic (float: one rounding per row, the library's
+// order); row 0 of I is zero.  I has H+1 rows; input row y lives at I[(y+1)*PW].  One lane per column; the loads of a
+// group of rows are issued together, the sums and stores follow.
+template <class T>
 __global__ __launch_bounds__(64) void sad_col_prefix_kernel(int* __restrict__ Ibase, int H, int PW, size_t tableStride)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= PW) return;
-    int* I = Ibase + (size_t)blockIdx.y * tableStride;
-    int run = 0;
-    // rows are stored shifted by one: input row y lives at I[(y+1)*PW]
-    for (int y = 1; y <= H; y++) {
-        run += I[(size_t)y * PW + x];
-        I[(size_t)y * PW + x] = run;
+    int* I = Ibase + (size_t)blockIdx.y * tableStride + x;
+    T run = 0;
+    auto put = [&](int y) {
+        int bits;
+        __builtin_memcpy(&bits, &run, 4);
+        I[(size_t)y * PW] = bits;
+    };
+    int y = 1;
+    for (; y + 7 <= H; y += 8) {
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = I[(size_t)(y + q) * PW];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { run = run + (T)v[q]; put(y + q); }
     }
-    I[x] = 0;
+    for (; y <= H; y++) { run = run + (T)I[(size_t)y * PW]; put(y); }
+    I[0] = 0;
 }
+
+struct SatWta {
+    int H, W, PW, h, first, d0;
+    int legacy, clampT, T;       // legacy (stereomatch_1): interior pixels only, every corner inside the table, out = (char)(16 * index)
+    int k0;                      // index of the batch's first slice
+};
 
 // four-corner lookups of the nb tables of a batch against the running best (strict '<': the lowest
 // disparity wins ties, methods_disp.cpp:246-262)
-__global__ __launch_bounds__(256) void sad_inte_wta_kernel(const int* __restrict__ Ibase, size_t tableStride, int nb, int H, int W,
-                                                           int PW, int h, int first, int d0, int* __restrict__ best,
-                                                           u8* __restrict__ out, size_t op)
+template <class T>
+__global__ __launch_bounds__(256) void sad_inte_wta_kernel(const int* __restrict__ Ibase, size_t tableStride, int nb, SatWta a,
+                                                           int* __restrict__ best, int* __restrict__ bestIdx,
+                                                           u8* __restrict__ out, size_t op, int last)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, h = a.h, H = a.H, W = a.W, PW = a.PW;
     if (x >= W) return;
+    if (a.legacy && !(y >= h && y < H - h && x >= h && x < W - h)) { if (last) out[(size_t)y * op + x] = 0; return; }
     const bool xh = x + h <= W, xl = x - h >= 0, yh = y + h <= H, yl = y - h >= 0;   // a corner outside the table reads 0
     const size_t i = (size_t)y * W + x;
-    int b = first ? 0 : best[i];
-    int bd = first ? 0 : out[(size_t)y * op + x];
-    bool have = !first;
+    T b = 0;
+    int bk = 0;
+    if (!a.first) { const int bits = best[i]; __builtin_memcpy(&b, &bits, 4); bk = bestIdx[i]; }
+    bool have = !a.first;
+    auto at = [&](const int* I, int yy, int xx) -> T { const int bits = I[(size_t)yy * PW + xx]; T v; __builtin_memcpy(&v, &bits, 4); return v; };
     for (int k = 0; k < nb; k++) {
         const int* I = Ibase + (size_t)k * tableStride;
-        int c = 0;
-        if (xh && yh) c += I[(size_t)(y + h) * PW + x + h];
-        if (xh && yl) c -= I[(size_t)(y - h) * PW + x + h];
-        if (xl && yh) c -= I[(size_t)(y + h) * PW + x - h];
-        if (xl && yl) c += I[(size_t)(y - h) * PW + x - h];
-        if (!have || c < b) { b = c; bd = (d0 + k) & 0xFF; have = true; }
+        T c = xh && yh ? at(I, y + h, x + h) : (T)0;
+        c = c - (xh && yl ? at(I, y - h, x + h) : (T)0);
+        c = c - (xl && yh ? at(I, y + h, x - h) : (T)0);
+        c = c + (xl && yl ? at(I, y - h, x - h) : (T)0);
+        if (!have || c < b) { b = c; bk = a.k0 + k; have = true; }
     }
-    best[i] = b; out[(size_t)y * op + x] = (u8)bd;
+    if (last) {
+        int r = a.legacy ? 16 * (a.clampT ? min(bk, a.T) : bk) : a.d0 + bk;
+        out[(size_t)y * op + x] = (u8)(r & 0xFF);
+    } else {
+        int bits;
+        __builtin_memcpy(&bits, &b, 4);
+        best[i] = bits; bestIdx[i] = bk;
+    }
 }
 
 // number of integral tables processed per batch: as many as fit half a gigabyte
@@ -422,23 +472,55 @@ int md_sad_inte_tables(int H, int W, int D)
     return (int)n;
 }
 
-// I: md_sad_inte_tables() tables of (H+1)*(W+1) ints, best: H*W ints of device scratch
-int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
-                int minD, int maxD, int off0, int offStep, int win, u8* out, size_t op, int* I, int* best)
+// I: md_sad_inte_tables() tables of (H+1)*(W+1) words, best: 2*H*W words of device scratch
+static int sat_run(hipStream_t s, const SatSlices& g, int H, int D, SatWta w, bool floatTables, u8* out, size_t op, int* I, int* best)
 {
+    const int W = g.W;
     MD_REQUIRE((double)H * W * 255.0 < 2147483647.0, MDISP_E_RANGE, "integral table overflows 32 bits for %dx%d", W, H);
-    const int PW = W + 1, D = maxD - minD + 1;
+    // the float row sums are formed as integers: exact (and equal to the library's float `s`) below 2^24
+    MD_REQUIRE(!floatTables || (double)W * 255.0 < 16777216.0, MDISP_E_RANGE, "image wider than 65793 columns");
+    const int PW = W + 1;
     const int n = md_sad_inte_tables(H, W, D);
     const size_t stride = (size_t)(H + 1) * PW;
+    w.H = H; w.W = W; w.PW = PW;
     for (int k0 = 0; k0 < D; k0 += n) {
         const int nb = D - k0 < n ? D - k0 : n;
-        sad_row_prefix_kernel<<<dim3(H, nb), 256, 0, s>>>(ref, rp, pad, pp, W, off0 + k0 * offStep, offStep, I + PW, PW, stride);
-        sad_col_prefix_kernel<<<dim3((PW + 63) / 64, nb), 64, 0, s>>>(I, H, PW, stride);
-        dim3 grid((W + 255) / 256, H);
-        sad_inte_wta_kernel<<<grid, 256, 0, s>>>(I, stride, nb, H, W, PW, win / 2, k0 == 0, minD + k0, best, out, op);
+        sad_row_prefix_kernel<<<dim3(H, nb), 256, 0, s>>>(g, k0, I + PW, PW, stride);
+        const dim3 gc((PW + 63) / 64, nb), grid((W + 255) / 256, H);
+        w.first = k0 == 0; w.k0 = k0;
+        const int last = k0 + nb >= D;
+        if (floatTables) {
+            sad_col_prefix_kernel<float><<<gc, 64, 0, s>>>(I, H, PW, stride);
+            sad_inte_wta_kernel<float><<<grid, 256, 0, s>>>(I, stride, nb, w, best, best + (size_t)H * W, out, op, last);
+        } else {
+            sad_col_prefix_kernel<int><<<gc, 64, 0, s>>>(I, H, PW, stride);
+            sad_inte_wta_kernel<int><<<grid, 256, 0, s>>>(I, stride, nb, w, best, best + (size_t)H * W, out, op, last);
+        }
     }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
+}
+
+int md_sad_inte(hipStream_t s, const u8* ref, size_t rp, const u8* pad, size_t pp, int H, int W,
+                int minD, int maxD, int off0, int offStep, int win, int floatTables, u8* out, size_t op, int* I, int* best)
+{
+    SatSlices g{};
+    g.ref = ref; g.rp = rp; g.oth = pad; g.op = pp; g.W = W; g.kind = 0; g.off0 = off0; g.offStep = offStep; g.minD = minD;
+    SatWta w{};
+    w.h = win / 2; w.d0 = minD;
+    return sat_run(s, g, H, maxD - minD + 1, w, floatTables != 0, out, op, I, best);
+}
+
+// the _inteOpti matchers of namespace stereomatch_1: difference 0 left of the candidate's offset, interior pixels only,
+// out = (char)(16 * index) with the index clamped to T by the "T" variants
+int md_legacy_inte(hipStream_t s, const u8* L, size_t lp, const u8* R, size_t rp, int H, int W, int minD, int numD, int win,
+                   int square, int clampT, int T, int floatTables, u8* out, size_t op, int* I, int* best)
+{
+    SatSlices g{};
+    g.ref = L; g.rp = lp; g.oth = R; g.op = rp; g.W = W; g.kind = 1; g.minD = minD; g.square = square;
+    SatWta w{};
+    w.h = win / 2; w.legacy = 1; w.clampT = clampT; w.T = T;
+    return sat_run(s, g, H, numD, w, floatTables != 0, out, op, I, best);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -176,11 +176,16 @@ int mdisp_census_stereo(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, 
 
 /* computeSAD_inteOpti / computeSAD_BFOpti, methods_disp.h:43-44, methods_disp.cpp:207-408.
  * out: CV_8U HxW (value stored modulo 256 like the reference's .at<char>).
- * mdisp_sad_inte sums in exact 32-bit integer tables; the reference's integral(..., CV_32F) tables (:238, :282) are
- * exact only while their entries stay below 2^24 (a 255-valued image of more than 65793 pixels can exceed it), so on
- * larger images the reference's own four-corner differences carry float rounding that this function does not reproduce:
- * identical results are guaranteed below that size only.  The same holds for the stereomatch_1 *_inteOpti variants. */
+ * mdisp_sad_inte follows the reference's integral(..., CV_32F) tables (:238, :282) in their own arithmetic: per row a
+ * float running sum s, sum[y+1][x+1] = sum[y][x+1] + s, the four corners combined left to right in float (:253-256),
+ * zero outside the table (getMatVal, :159-171).  Such tables round once an entry passes 2^24 (a 255-valued difference
+ * image does after 65793 pixels; main() works at 1280x720) and the winner follows the rounding -- reproduced here.
+ * mdisp_sad_inte_mode selects the arithmetic per call: MDISP_SAT_F32 (the above) or MDISP_SAT_INT, exact 32-bit integer
+ * tables with the same 2h x 2h footprint and zero-outside rule; the two agree while every table entry stays below 2^24.
+ * MDISP_TUNE_SAT_INT_TABLES switches mdisp_sad_inte and the stereomatch_1 *_inteOpti matchers to the integer tables. */
+enum { MDISP_SAT_F32 = 0, MDISP_SAT_INT = 1 };
 int mdisp_sad_inte(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
+int mdisp_sad_inte_mode(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, int table_mode, mdisp_image* out);
 int mdisp_sad_box(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, const mdisp_param* p, mdisp_image* out);
 
 /* getGuidedFilter / _wgif / _egif / _skwgif2, gifs.h:17-33, gifs.cpp:47-135,227-273,376-409,537-617.
@@ -462,7 +467,8 @@ enum {
     MDISP_TUNE_SGM_HAND_RING = 11,     /* row bands: entries of the hand-off ring (2..32, a power of two; default 32) */
     MDISP_TUNE_SGM_MEET_MAX = 12,      /* row bands: largest batch whose two sweeps start from both image edges at once (default: any) */
     MDISP_TUNE_SGM_ONE_LAUNCH = 13,    /* row bands: 0 = the two sweep directions as two launches per phase, 1 = both directions and both roles in one launch; default: one launch up to 96 pairs */
-    MDISP_TUNE_COUNT = 14
+    MDISP_TUNE_SAT_INT_TABLES = 14,    /* 1: mdisp_sad_inte and the stereomatch_1 _inteOpti matchers sum in exact integer tables instead of the reference's CV_32F ones */
+    MDISP_TUNE_COUNT = 15
 };
 int mdisp_tuning_set(int key, int value);
 int mdisp_tuning_get(int key);

@@ -69,6 +69,9 @@ enum {
 };
 int orc_legacy_disparity(const uint8_t* L, const uint8_t* R, int H, int W, int method, int winSize, int T, int minD, int numD,
                          uint8_t* out);
+/* the three _inteOpti kinds through CV_32F summed-area tables in the library's accumulation order */
+int orc_legacy_inte_f32(const uint8_t* L, const uint8_t* R, int H, int W, int method, int winSize, int T, int minD, int numD,
+                        uint8_t* out);
 
 /* cv::StereoSGBM parameters (create() argument order) */
 enum { ORC_SGBM_MODE_SGBM = 0, ORC_SGBM_MODE_HH = 1 };

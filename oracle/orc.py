@@ -378,6 +378,15 @@ def legacy_disparity(L, R, method, winSize=7, threshold_T=30, minDisparity=0, nu
     return None if rc else out
 
 
+def legacy_inte_f32(L, R, method, winSize=7, threshold_T=30, minDisparity=0, numDisparity=30):
+    """The _inteOpti kinds with the reference's CV_32F integral tables (rounding above 2^24 included) -> uint8."""
+    L, R = _u8(L), _u8(R)
+    H, W = L.shape
+    out = np.empty((H, W), np.uint8)
+    rc = lib().orc_legacy_inte_f32(_p(L), _p(R), H, W, method, winSize, threshold_T, minDisparity, numDisparity, _p(out))
+    return None if rc else out
+
+
 def ncc_disparity(L, R, is_left=True, winSize=7, minDisparity=0, numDisparity=30):
     """stereomatch_1::computeNCC, map overload (methods/method_StereoMatching.cpp:915-1015) -> float32, or None where the
     reference refuses (even window)."""

@@ -90,3 +90,58 @@ int orc_legacy_disparity(const uint8_t* L, const uint8_t* R, int H, int W, int m
         }
     return 0;
 }
+
+/*
+ * The _inteOpti matchers with the reference's own table arithmetic (method_StereoMatching.cpp:155-221, 437-504,
+ * 722-789): per candidate the difference image (0 left of column minDisparity + k; SSD: pow(.,2) saturated to 8 bits),
+ * integral(..., CV_32F) filled in the library's scalar order -- per row a float running sum s,
+ * sum[y+1][x+1] = sum[y][x+1] + s -- then at interior pixels
+ * I(j+h,i+h) - I(j-h,i+h) - I(j+h,i-h) + I(j-h,i-h) evaluated left to right in float, first minimum (minMaxLoc),
+ * out = (char)(16 * index) (index clamped to T by STAD).  Equal to orc_legacy_disparity while every table entry stays
+ * below 2^24; above, the float entries round and the winner follows them.
+ */
+int orc_legacy_inte_f32(const uint8_t* L, const uint8_t* R, int H, int W, int method, int winSize, int T, int minD, int numD,
+                        uint8_t* out)
+{
+    if (!L || !R || !out || numD <= 0 || minD < 0) return -1;
+    if (method != ORC_LEGACY_SAD_INTE && method != ORC_LEGACY_STAD_INTE && method != ORC_LEGACY_SSD_INTE) return -4;
+    if (winSize <= 0 || winSize % 2 == 0) return -3;
+    if (minD + numD - 1 >= W) return -2;
+    const int clampT = method == ORC_LEGACY_STAD_INTE, square = method == ORC_LEGACY_SSD_INTE;
+    const int h = winSize / 2, IW = W + 1;
+    const long N = (long)H * W;
+    memset(out, 0, (size_t)N);
+    float* I = (float*)calloc((size_t)IW * (H + 1), sizeof(float));
+    float* best = (float*)malloc(sizeof(float) * N);
+    int* bestK = (int*)calloc((size_t)N, sizeof(int));
+    for (int k = 0; k < numD; k++) {
+        const int d = minD + k;
+        for (int y = 0; y < H; y++) {
+            float s = 0.f;
+            for (int x = 0; x < W; x++) {
+                int v = x >= d ? iabs(L[(long)y * W + x] - R[(long)y * W + x - d]) : 0;
+                if (square) { v = v * v; if (v > 255) v = 255; }
+                s += (float)v;
+                I[(long)(y + 1) * IW + x + 1] = I[(long)y * IW + x + 1] + s;
+            }
+        }
+#pragma omp parallel for
+        for (int j = h; j < H - h; j++)
+            for (int i = h; i < W - h; i++) {
+                volatile float c = I[(long)(j + h) * IW + i + h];
+                c = c - I[(long)(j - h) * IW + i + h];
+                c = c - I[(long)(j + h) * IW + i - h];
+                c = c + I[(long)(j - h) * IW + i - h];
+                const long p = (long)j * W + i;
+                if (k == 0 || c < best[p]) { best[p] = c; bestK[p] = k; }
+            }
+    }
+    for (int j = h; j < H - h; j++)
+        for (int i = h; i < W - h; i++) {
+            int b = bestK[(long)j * W + i];
+            if (clampT && b > T) b = T;
+            out[(long)j * W + i] = (uint8_t)(16 * b);
+        }
+    free(I); free(best); free(bestK);
+    return 0;
+}

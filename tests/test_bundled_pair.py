@@ -77,6 +77,6 @@ def test_library_equals_oracle_on_the_bundled_pair(api, orc, pair, calib):
     p = api.StereoMatchParam(imgLeft=L, imgRight=R, winSize=7, minDisparity=0, maxDisparity=63, isDispLeft=True)
     assert np.array_equal(api.censusStereo(p, api.BASIC_CENSUS, api.AGG_BOX), orc.census_stereo(L, R, 7, 0, 63, True, orc.BASIC_CENSUS, orc.AGG_BOX))
     assert np.array_equal(api.computeSAD_BFOpti(p), orc.sad_box(L, R, 7, 0, 63, True))
-    assert np.array_equal(api.computeSAD_inteOpti(p), orc.sad_inte(L, R, 7, 0, 63, True, orc.SAT_INT))
+    assert np.array_equal(api.computeSAD_inteOpti(p), orc.sad_inte(L, R, 7, 0, 63, True, orc.SAT_F32))
     sp = api.sgbm_params(0, 64, 8, 32, 10, 1, 8, 1)
     assert np.array_equal(api.sgbm_compute(L, R, sp), orc.sgm(L, R, 0, 64, 8, 32, 10, 1, 8, 1))
