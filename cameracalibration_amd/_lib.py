@@ -64,6 +64,7 @@ EXPORTS = [
     "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
     "mdisp_context_device_bytes", "mdisp_sad_inte_mode",
+    "mdisp_cost_sad_d", "mdisp_guided_filter_multi", "mdisp_adaptive_weight_guidedf",
 ]
 
 _lib = None
@@ -146,6 +147,9 @@ def load():
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
     lib.mdisp_context_device_bytes.argtypes = [vp]
+    lib.mdisp_cost_sad_d.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_int, img]
+    lib.mdisp_guided_filter_multi.argtypes = [vp, img, img, C.c_int, C.c_double, C.c_int, img]
+    lib.mdisp_adaptive_weight_guidedf.argtypes = [vp, img, img, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, img]
     lib.mdisp_context_device_bytes.restype = C.c_size_t
     sbp = P(mdisp_stereobm_params)
     lib.mdisp_stereobm_compute.argtypes = [vp, img, img, sbp, img]

@@ -21,8 +21,9 @@ AGG_NONE, AGG_BOX, AGG_SQRBOX, AGG_GUIDED = range(4)
 # GIF_TYPE, gifs.h:4-13
 GIF, WGIF, EGIF, SKWGIF, OURS_GIF, OURS_GIF2, OURS_GIF3 = range(7)
 COST_VOLUME, COST_CENSUS, COST_ABSDIFF = range(3)
-# StereoMatchingAlgorithms, methods/parametersStereo.h:11-24 (the entries built here)
-BM, SGBM = 0, 1
+# StereoMatchingAlgorithms, methods/parametersStereo.h:11-24
+(BM, SGBM, ADAPTIVE_WEIGHT, ADAPTIVE_WEIGHT_8DIRECT, ADAPTIVE_WEIGHT_GEODESIC, ADAPTIVE_WEIGHT_BILATERAL_GRID, ADAPTIVE_WEIGHT_BLO1,
+ ADAPTIVE_WEIGHT_GUIDED_FILTER, ADAPTIVE_WEIGHT_GUIDED_FILTER_2, ADAPTIVE_WEIGHT_GUIDED_FILTER_3, ADAPTIVE_WEIGHT_MEDIAN) = range(11)
 
 
 @dataclass
@@ -391,11 +392,14 @@ def getDisparity_BM(srcLeft, srcRight, ctx=None):
 
 
 def stereoMatching(srcLeft, srcRight, algorithmType=SGBM, ctx=None):
-    """methods/methods.cpp:1776-1813: the BM and SGBM entries (the adaptive-weight research variants are not built)."""
+    """methods/methods.cpp:1776-1813: the BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER entries (the other adaptive-weight
+    research variants are not built)."""
     if algorithmType == BM:
         return getDisparity_BM(srcLeft, srcRight, ctx)
+    if algorithmType == ADAPTIVE_WEIGHT_GUIDED_FILTER:
+        return stereomatch_1.computeAdaptiveWeight_GuidedF(srcLeft, srcRight, DISPARITY_LEFT, 0.01, 15, 10, 150, ctx=ctx)   # :1801-1803
     if algorithmType != SGBM:
-        raise NotImplementedError("only the BM and SGBM entries of stereoMatching are built")
+        raise NotImplementedError("only the BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER entries of stereoMatching are built")
     return getDisparity_SGBM(srcLeft, srcRight, ctx)
 
 
@@ -559,6 +563,23 @@ def synth_pair(seed, rows, cols, numDisp):
  LEGACY_SD, LEGACY_SSD, LEGACY_SSD_INTE, LEGACY_SSD_BF) = range(12)
 
 
+def _guided_multi(guidedImg, inputP, r, eps, variant, ctx):
+    g = np.ascontiguousarray(guidedImg, np.uint8)
+    P = np.ascontiguousarray(inputP)
+    if P.dtype != np.uint8:
+        P = np.ascontiguousarray(P, np.float32)
+    if g.shape[:2] != P.shape[:2]:
+        return None
+    out = np.empty(g.shape[:2], np.float32)
+    check(load().mdisp_guided_filter_multi(_ctx(ctx), C.byref(image(g)), C.byref(image(P)), r, eps, variant, C.byref(image(out))))
+    return out
+
+
+def getGuidedFilter_multi(guidedImg, inputP, r, eps, ctx=None):
+    """disp_method/gifs.cpp:47-135 with a 3- or 6-channel uint8 guide -> float32, None on a size mismatch."""
+    return _guided_multi(guidedImg, inputP, r, eps, 0, ctx)
+
+
 def _legacy(method, leftImg, rightImg, winSize, threshold_T, minDisparity, numDisparity, ctx):
     L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
     if method not in (LEGACY_AD, LEGACY_TAD, LEGACY_SD) and winSize % 2 == 0:
@@ -575,6 +596,37 @@ DISPARITY_LEFT, DISPARITY_RIGHT = 0, 1          # methods/parametersStereo.h:5-9
 
 class stereomatch_1:
     """The reference's namespace of the same name: same function names, argument order and defaults."""
+
+    @staticmethod
+    def getCostSAD_d(leftImg, rightImg, disparity, dispType=DISPARITY_LEFT, winSize=35, ctx=None):
+        """methods/method_StereoMatching.h:171: one of the views is the bordered (wider) one -> float32 slice, or None where
+        the reference returns an empty image."""
+        L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+        if winSize % 2 == 0:
+            print("winsize must be odd")
+            return None
+        ref, oth = (L, R) if dispType == DISPARITY_LEFT else (R, L)
+        if oth.shape[1] <= ref.shape[1]:
+            return None
+        out = np.empty(ref.shape[:2], np.float32)
+        check(load().mdisp_cost_sad_d(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), disparity, 1 if dispType == DISPARITY_LEFT else 0,
+                                      winSize, C.byref(image(out))))
+        return out
+
+    @staticmethod
+    def getGuidedFilter(guidedImg, inputP, r, eps, ctx=None):
+        """methods/method_StereoMatching.h:178 with a 3- or 6-channel uint8 guide -> float32, None on a size mismatch."""
+        return _guided_multi(guidedImg, inputP, r, eps, 1, ctx)
+
+    @staticmethod
+    def computeAdaptiveWeight_GuidedF(leftImg, rightImg, dispType=DISPARITY_LEFT, eps=0.01, winSize=35, minDisparity=186, numDisparity=144,
+                                      ctx=None):
+        """methods/method_StereoMatching.h:179-181 on H x W x 3 uint8 images -> float32 map."""
+        L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+        out = np.empty(L.shape[:2], np.float32)
+        check(load().mdisp_adaptive_weight_guidedf(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), 1 if dispType == DISPARITY_LEFT else 0,
+                                                   eps, winSize, minDisparity, numDisparity, C.byref(image(out))))
+        return out
 
     @staticmethod
     def computeNCC(leftImg, rightImg, dispType=DISPARITY_LEFT, winSize=7, minDisparity=0, numDisparity=30, ctx=None, cost_ds=None):

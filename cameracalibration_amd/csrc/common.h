@@ -187,6 +187,16 @@ int md_gif_band_stats(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpit
                       const u8* ref, size_t rp, const u8* pad, size_t pp, int off0, int offStep, int costKind, int yA, int yB,
                       float* minmax, double* steerMax);
 
+// gif_mc.hip: guided filter with a multi-channel guide, getCostSAD_d, computeAdaptiveWeight_GuidedF
+int md_mc_check_window(int r);
+size_t md_mc_scratch_bytes(int H, int W, int cn, int n, int Wa, int Wb);
+size_t md_asw_guidedf_bytes(int H, int W, int cn, int minD, int numD);
+int md_asw_guidedf(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int cn, int isLeft, double eps, int win,
+                   int minD, int numD, float* dDisp, void* ws);
+int md_cost_sad_d(hipStream_t s, const u8* ref, size_t rp, const u8* oth, size_t op, int H, int W, int off, int win, float* out);
+int md_guided_filter_mc(hipStream_t s, const u8* guide, size_t gp, int cn, const float* dP, int H, int W, int r, double eps, int variant,
+                        float* dOut, void* scratch);
+
 // cost kinds of md_cost_box_wta
 enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };
 // output kinds

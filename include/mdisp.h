@@ -436,6 +436,35 @@ int mdisp_asw_gifs_band_stats_dev(mdisp_ctx*, const uint8_t* d_left, const uint8
                                   const mdisp_param* p, int gif_type, int cost_source, int row_begin, int row_end,
                                   float* cost_minmax, double* steer_max);
 
+/* ---- the guided-filter matcher of namespace stereomatch_1 (methods/method_StereoMatching.h, .cpp:3288-3781) ----
+ *
+ * mdisp_cost_sad_d: stereomatch_1::getCostSAD_d (.cpp:3288-3349).  One of the two views is the one the caller bordered with
+ * copyMakeBorder(BORDER_REFLECT) and is wider: the right one for is_left (compared at column cols_right - cols - disparity),
+ * the left one otherwise (at column disparity).  CV_8U, 1 or 3 channels (BGR -> gray as the reference does); out: CV_32F of
+ * the narrower view's size = boxFilter(|difference|, winSize x winSize, normalised).  MDISP_E_BADARG where the reference
+ * returns an empty image (even window, other view not wider). */
+int mdisp_cost_sad_d(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, int disparity, int is_left, int winSize,
+                     mdisp_image* out);
+
+/* getGuidedFilter with a 3- or 6-channel CV_8U guide (single-channel guides: mdisp_guided_filter).  P: CV_8U or CV_32F,
+ * one channel; out: CV_32F.  Guide and P are min-max normalised first (one minimum / maximum over all guide channels),
+ * every channel is filtered on its own, a = cov / (var + eps) per channel, b = mean(P) - dot(a, mean(G)),
+ * out = dot(box(a), G) + box(b).
+ * MDISP_GIF_MC_GIFS: disp_method/gifs.cpp:47-135 with multiChl_to_oneChl_mul (:8-45).
+ * MDISP_GIF_MC_STEREOMATCH: the twin methods/method_StereoMatching.cpp:3612-3672, whose regulariser is
+ * (var / var) * eps -- 0 where the variance is 0 (cv::divide), and a = 0 there. */
+enum { MDISP_GIF_MC_GIFS = 0, MDISP_GIF_MC_STEREOMATCH = 1 };
+int mdisp_guided_filter_multi(mdisp_ctx*, const mdisp_image* guide, const mdisp_image* P, int r, double eps, int variant,
+                              mdisp_image* out);
+
+/* stereomatch_1::computeAdaptiveWeight_GuidedF (.cpp:3685-3781; stereoMatching(ADAPTIVE_WEIGHT_GUIDED_FILTER) calls it with
+ * DISPARITY_LEFT, 0.01, 15, 10, 150, methods/methods.cpp:1801-1803).  L / R: CV_8UC3 of equal size; per candidate the
+ * getCostSAD_d slice is filtered with the six-channel guide [left, right] of the two views aligned at the candidate, then
+ * the first minimum wins; out: CV_32F map holding minDisparity + index.  Gray input: MDISP_E_UNSUPPORTED (the reference's
+ * 2-channel guide fails inside multiChl_to_oneChl_mul). */
+int mdisp_adaptive_weight_guidedf(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, int is_left, double eps, int winSize,
+                                  int minDisparity, int numDisparity, mdisp_image* out);
+
 /* time of the most recent call's dominant kernel on this context, measured with HIP events on
  * the context's stream (milliseconds); which = 0: whole call, 1: SGM path aggregation (every scan
  * and sweep kernel of the call), 2: the separate winner-take-all kernel of the per-direction

@@ -164,6 +164,13 @@ inline cv::Mat computeSD(cv::Mat l, cv::Mat r, int minDisparity = 0, int numDisp
 inline cv::Mat computeSSD(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD(l, r, winSize, minDisparity, numDisparity); }
 inline cv::Mat computeSSD_inteOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_inteOpti(l, r, winSize, minDisparity, numDisparity); }
 inline cv::Mat computeSSD_BFOpti(cv::Mat l, cv::Mat r, int winSize = 7, int minDisparity = 0, int numDisparity = 30) { return mdisp::stereomatch_1::computeSSD_BFOpti(l, r, winSize, minDisparity, numDisparity); }
+// methods/method_StereoMatching.h:171, 178-181
+inline cv::Mat getCostSAD_d(cv::Mat leftImg, cv::Mat rightImg, int disparity, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, int winSize = 35)
+{ return mdisp::stereomatch_1::getCostSAD_d(leftImg, rightImg, disparity, (mdisp::stereomatch_1::DisparityType)(int)dispType, winSize); }
+inline cv::Mat getGuidedFilter(cv::Mat guidedImg, cv::Mat inputP, int r, double eps) { return mdisp::stereomatch_1::getGuidedFilter(guidedImg, inputP, r, eps); }
+inline cv::Mat computeAdaptiveWeight_GuidedF(cv::Mat leftImg, cv::Mat rightImg, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, double eps = 0.01,
+                                             int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return mdisp::stereomatch_1::computeAdaptiveWeight_GuidedF(leftImg, rightImg, (mdisp::stereomatch_1::DisparityType)(int)dispType, eps, winSize, minDisparity, numDisparity); }
 }  // namespace stereomatch_1
 
 #endif  // MDISP_CV_HPP

@@ -219,8 +219,22 @@ template <class M> M guidedFilter_(M guide, M P, int r, double eps, int type, co
                                       beta ? &bv : nullptr));
     return out;
 }
+// a 3- or 6-channel guide takes the multi-channel form of gifs.cpp:63-134 (per-channel coefficients, dot products)
 template <class M> M getGuidedFilter(M guidedImg, M inputP, int r, double eps)
-{ return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_GIF, nullptr, 0, 0.0, nullptr); }
+{
+    typedef mat_traits<M> T;
+    mdisp_image g = T::view(guidedImg);
+    if (g.channels == 3 || g.channels == 6) {
+        mdisp_image p = T::view(inputP);
+        if (g.rows != p.rows || g.cols != p.cols) return M();
+        M out;
+        T::create(out, g.rows, g.cols, MDISP_32F, 1);
+        mdisp_image o = T::view(out);
+        detail::check(mdisp_guided_filter_multi(Context::forThisThread().handle(), &g, &p, r, eps, MDISP_GIF_MC_GIFS, &o));
+        return out;
+    }
+    return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_GIF, nullptr, 0, 0.0, nullptr);
+}
 template <class M> M getGuidedFilter_wgif(M guidedImg, M inputP, int r, double eps)
 { return guidedFilter_<M>(guidedImg, inputP, r, eps, MDISP_WGIF, nullptr, 0, 0.0, nullptr); }
 template <class M> M getGuidedFilter_egif(M guidedImg, M inputP, int r, double eps, M& beta)
@@ -383,14 +397,31 @@ enum StereoMatchingAlgorithms {
     ADAPTIVE_WEIGHT_MEDIAN = 10
 };
 
-// methods/methods.h:27, methods.cpp:1776-1813.  BM and SGBM run on the GPU; the adaptive-weight research variants of
-// namespace stereomatch_1 are not built and leave disparityMap untouched after a message.
+namespace detail {
+// stereomatch_1::computeAdaptiveWeight_GuidedF, methods/method_StereoMatching.cpp:3685-3781 (CV_8UC3 views -> CV_32F map)
+template <class M> M adaptive_weight_guidedf(M leftImg, M rightImg, bool isLeft, double eps, int winSize, int minDisparity, int numDisparity)
+{
+    typedef mat_traits<M> T;
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    M out;
+    T::create(out, l.rows, l.cols, MDISP_32F, 1);
+    mdisp_image o = T::view(out);
+    check(mdisp_adaptive_weight_guidedf(Context::forThisThread().handle(), &l, &r, isLeft, eps, winSize, minDisparity, numDisparity, &o));
+    return out;
+}
+}  // namespace detail
+
+// methods/methods.h:27, methods.cpp:1776-1813.  BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER run on the GPU; the other
+// adaptive-weight research variants of namespace stereomatch_1 are not built and leave disparityMap untouched after a message.
 template <class M> void stereoMatching(M srcLeft, M srcRight, M& disparityMap, StereoMatchingAlgorithms algorithmType)
 {
     switch (algorithmType) {
     case BM: getDisparity_BM(srcLeft, srcRight, disparityMap); break;
     case SGBM: getDisparity_SGBM(srcLeft, srcRight, disparityMap); break;
-    default: std::cout << "stereoMatching: algorithm " << (int)algorithmType << " is not built (BM and SGBM are)" << std::endl;
+    case ADAPTIVE_WEIGHT_GUIDED_FILTER:      // methods.cpp:1801-1803
+        disparityMap = detail::adaptive_weight_guidedf(srcLeft, srcRight, true, 0.01, 15, 10, 150);
+        break;
+    default: std::cout << "stereoMatching: algorithm " << (int)algorithmType << " is not built (BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER are)" << std::endl;
     }
 }
 
@@ -533,6 +564,38 @@ template <class M> M computeSSD_inteOpti(M leftImg, M rightImg, int winSize = 7,
 { return legacy_<M>(MDISP_LEGACY_SSD_INTE, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
 template <class M> M computeSSD_BFOpti(M leftImg, M rightImg, int winSize = 7, int minDisparity = 0, int numDisparity = 30)
 { return legacy_<M>(MDISP_LEGACY_SSD_BF, leftImg, rightImg, winSize, 0, minDisparity, numDisparity); }
+// methods/method_StereoMatching.h:171: one of the views is the one the caller bordered (wider); empty image where the
+// reference returns one (even window, other view not wider)
+template <class M> M getCostSAD_d(M leftImg, M rightImg, int disparity, DisparityType dispType = DISPARITY_LEFT, int winSize = 35)
+{
+    typedef mat_traits<M> T;
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    if (winSize % 2 == 0) { std::cout << "winsize must be odd" << std::endl; return M(); }
+    const mdisp_image& ref = dispType == DISPARITY_LEFT ? l : r;
+    const mdisp_image& oth = dispType == DISPARITY_LEFT ? r : l;
+    if (oth.cols <= ref.cols) return M();
+    M out;
+    T::create(out, ref.rows, ref.cols, MDISP_32F, 1);
+    mdisp_image o = T::view(out);
+    detail::check(mdisp_cost_sad_d(Context::forThisThread().handle(), &l, &r, disparity, dispType == DISPARITY_LEFT, winSize, &o));
+    return out;
+}
+// methods/method_StereoMatching.h:178 with a 3- or 6-channel CV_8U guide; empty image on a size mismatch
+template <class M> M getGuidedFilter(M guidedImg, M inputP, int r, double eps)
+{
+    typedef mat_traits<M> T;
+    mdisp_image g = T::view(guidedImg), p = T::view(inputP);
+    if (g.rows != p.rows || g.cols != p.cols) return M();
+    M out;
+    T::create(out, g.rows, g.cols, MDISP_32F, 1);
+    mdisp_image o = T::view(out);
+    detail::check(mdisp_guided_filter_multi(Context::forThisThread().handle(), &g, &p, r, eps, MDISP_GIF_MC_STEREOMATCH, &o));
+    return out;
+}
+// methods/method_StereoMatching.h:179-181
+template <class M> M computeAdaptiveWeight_GuidedF(M leftImg, M rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 0.01,
+                                                   int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return detail::adaptive_weight_guidedf(leftImg, rightImg, dispType == DISPARITY_LEFT, eps, winSize, minDisparity, numDisparity); }
 }  // namespace stereomatch_1
 
 }  // namespace mdisp

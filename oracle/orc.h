@@ -73,6 +73,15 @@ int orc_legacy_disparity(const uint8_t* L, const uint8_t* R, int H, int W, int m
 int orc_legacy_inte_f32(const uint8_t* L, const uint8_t* R, int H, int W, int method, int winSize, int T, int minD, int numD,
                         uint8_t* out);
 
+/* stereomatch_1::getCostSAD_d, getGuidedFilter with a multi-channel guide, computeAdaptiveWeight_GuidedF
+ * (methods/method_StereoMatching.cpp:3288-3349, 3612-3672, 3685-3781; disp_method/gifs.cpp:8-135) */
+int orc_cost_sad_d(const uint8_t* left, int leftW, const uint8_t* right, int rightW, int H, int disparity, int isLeft, int winSize,
+                   float* out);
+void orc_guided_filter_mc(const float* G /* cn planes, normalised */, int cn, const float* P, int H, int W, int r, double eps,
+                          int variant, float* out);
+int orc_adaptive_weight_guidedf(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int isLeft, double eps, int winSize, int minD,
+                                int numD, float* depth);
+
 /* cv::StereoSGBM parameters (create() argument order) */
 enum { ORC_SGBM_MODE_SGBM = 0, ORC_SGBM_MODE_HH = 1 };
 typedef struct {

@@ -387,6 +387,45 @@ def legacy_inte_f32(L, R, method, winSize=7, threshold_T=30, minDisparity=0, num
     return None if rc else out
 
 
+def cost_sad_d(left, right, disparity, is_left, winSize):
+    """stereomatch_1::getCostSAD_d on gray images of which one is bordered (wider) -> float32, or None where the
+    reference returns an empty image."""
+    left, right = _u8(left), _u8(right)
+    H = left.shape[0]
+    W = left.shape[1] if is_left else right.shape[1]
+    out = np.empty((H, W), np.float32)
+    rc = lib().orc_cost_sad_d(_p(left), left.shape[1], _p(right), right.shape[1], H, disparity, int(is_left), winSize, _p(out))
+    return None if rc else out
+
+
+def guided_filter_mc(guide, P, r, eps, variant=0):
+    """getGuidedFilter with an H x W x cn uint8 guide (normalised here with one min / max over all channels) and a
+    single-channel P; variant 0: gifs.cpp, 1: stereomatch_1 -> float32."""
+    g = np.ascontiguousarray(guide, np.uint8)
+    H, W, cn = g.shape
+    mn, mx = int(g.min()), int(g.max())
+    scale = 1.0 / (mx - mn) if mx - mn > np.finfo(np.float64).eps else 0.0
+    a, b = np.float32(scale), np.float32(0.0 - mn * scale)
+    G = np.ascontiguousarray(np.moveaxis(g.astype(np.float32) * a + b, 2, 0))
+    Pn = normalize_minmax(np.ascontiguousarray(P))
+    out = np.empty((H, W), np.float32)
+    lib().orc_guided_filter_mc(_p(G), cn, _p(Pn), H, W, r, C.c_double(eps), variant, _p(out))
+    return out
+
+
+def adaptive_weight_guidedf(L, R, is_left=True, eps=0.01, winSize=15, minDisparity=10, numDisparity=150):
+    """stereomatch_1::computeAdaptiveWeight_GuidedF on H x W x 3 uint8 images -> float32 map, or None where the
+    reference fails (gray input)."""
+    L = np.ascontiguousarray(L, np.uint8)
+    R = np.ascontiguousarray(R, np.uint8)
+    cn = 1 if L.ndim == 2 else L.shape[2]
+    H, W = L.shape[:2]
+    out = np.empty((H, W), np.float32)
+    rc = lib().orc_adaptive_weight_guidedf(_p(L), _p(R), H, W, cn, int(is_left), C.c_double(eps), winSize, minDisparity, numDisparity,
+                                           _p(out))
+    return None if rc else out
+
+
 def ncc_disparity(L, R, is_left=True, winSize=7, minDisparity=0, numDisparity=30):
     """stereomatch_1::computeNCC, map overload (methods/method_StereoMatching.cpp:915-1015) -> float32, or None where the
     reference refuses (even window)."""

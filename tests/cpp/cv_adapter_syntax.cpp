@@ -29,4 +29,8 @@ void use_every_boundary_function(cv::Mat l, cv::Mat r, std::string xml)
     std::vector<cv::Mat> slices;
     a = stereomatch_1::computeNCC(l, r); a = stereomatch_1::computeNCC(l, r, DISPARITY_RIGHT, 5, 2, 16);
     stereomatch_1::computeNCC(l, r, slices); stereomatch_1::computeNCC(l, r, slices, DISPARITY_LEFT, 7, 0, 30);
+    a = stereomatch_1::getCostSAD_d(l, r, 3); a = stereomatch_1::getCostSAD_d(l, r, 3, DISPARITY_RIGHT, 15);
+    a = stereomatch_1::getGuidedFilter(l, b, 15, 0.01);
+    a = stereomatch_1::computeAdaptiveWeight_GuidedF(l, r); a = stereomatch_1::computeAdaptiveWeight_GuidedF(l, r, DISPARITY_LEFT, 0.01, 15, 10, 150);
+    stereoMatching(l, r, a, mdisp::ADAPTIVE_WEIGHT_GUIDED_FILTER);
 }

@@ -88,6 +88,23 @@ int main(int argc, char** argv)
     if (fL.empty() || fR.empty()) return fail("empty postProcess_ output");
     std::fwrite(fL.data(), 4, (size_t)H * W, f);
     std::fwrite(fR.data(), 4, (size_t)H * W, f);
+    // the guided-filter matcher on a colour pair (channel c = gray value scaled by (4 - c) / 4), method_StereoMatching.h:179-181,
+    // and one of its cost slices (:171) on a bordered right view
+    Mat Lc(H, W, MDISP_8U, 3), Rc(H, W, MDISP_8U, 3), Rb(H, W + 8, MDISP_8U, 1);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < 3; c++) {
+                Lc.ptr<uint8_t>(y)[x * 3 + c] = (uint8_t)(L.at<uint8_t>(y, x) * (4 - c) / 4);
+                Rc.ptr<uint8_t>(y)[x * 3 + c] = (uint8_t)(R.at<uint8_t>(y, x) * (4 - c) / 4);
+            }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W + 8; x++) Rb.at<uint8_t>(y, x) = R.at<uint8_t>(y, x < 8 ? 7 - x : x - 8);       // BORDER_REFLECT on the left
+    Mat dGf = stereomatch_1::computeAdaptiveWeight_GuidedF(Lc, Rc, stereomatch_1::DISPARITY_LEFT, 0.01, 7, 0, 12);
+    Mat cSad = stereomatch_1::getCostSAD_d(L, Rb, 3, stereomatch_1::DISPARITY_LEFT, 5);
+    if (dGf.empty() || cSad.empty() || !stereomatch_1::getCostSAD_d(L, R, 3, stereomatch_1::DISPARITY_LEFT, 5).empty())
+        return fail("computeAdaptiveWeight_GuidedF / getCostSAD_d: empty output, or an unbordered view accepted");
+    std::fwrite(dGf.data(), 4, (size_t)H * W, f);
+    std::fwrite(cSad.data(), 4, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

@@ -42,7 +42,8 @@ def test_cv_adapter_names_every_boundary_function():
     for name in ("computeSAD_inteOpti", "computeSAD_BFOpti", "censusStereo", "asw_gifs", "countCensusImg", "countHummingDist",
                  "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "getGuidedFilter_ours_gif", "getGuidedFilter_ours_gif2",
                  "getGuidedFilter_ours_gif3", "steerFilter",
-                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam", "computeNCC"):
+                 "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam", "computeNCC",
+                 "getCostSAD_d", "computeAdaptiveWeight_GuidedF"):
         assert name in text
 
 
@@ -68,7 +69,14 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     dBm = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
     dDispatch = buf[o:o + 2 * n].view(np.int16).reshape(H, W); o += 2 * n
     fL = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
-    fR = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
+    fR = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    dGf = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    cSad = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
+    Lc = np.stack([(L.astype(np.int32) * (4 - c) // 4).astype(np.uint8) for c in range(3)], axis=-1)
+    Rc = np.stack([(R.astype(np.int32) * (4 - c) // 4).astype(np.uint8) for c in range(3)], axis=-1)
+    eGf = orc.adaptive_weight_guidedf(Lc, Rc, True, 0.01, 7, 0, 12)
+    assert (dGf != eGf).mean() < 2e-3                 # float winner-take-all: near-ties may differ
+    assert np.array_equal(cSad, orc.cost_sad_d(L, np.pad(R, ((0, 0), (8, 0)), mode="symmetric"), 3, True, 5))
     eL, eR = orc.postProcess_(L, R, dO, dO)
     assert np.abs(fL - eL).max() <= 1e-3 * max(1.0, float(np.abs(eL).max())) and np.abs(fR - eR).max() <= 1e-3 * max(1.0, float(np.abs(eR).max()))
     assert np.array_equal(dBm, orc.stereobm(L, R, 16, 9, minDisparity=2, textureThreshold=10, uniquenessRatio=25))
