@@ -4,7 +4,10 @@
 // the BORDER_REFLECT_101 box mean at the pixel) and scores a candidate with
 //     sum(l .* r) / (sum(l .* l) * sum(r .* r))        (float products, double sums, a PRODUCT of energies)
 // Here the means and energies are computed once per view, and the cross sums per (pixel, offset) in the same order
-// (row-major over the window, double accumulation of float products), so the values are the reference's bit for bit.
+// (row-major over the window, double accumulation of float products) as the CPU restatement this library is tested
+// against.  Parity with the reference itself is unpinned: cv::boxFilter, cv::sum and cv::normalize may order their
+// partial sums differently (or fuse a multiply-add), so a last-bit difference -- and with it a flipped strict '<' between
+// two nearly equal scores -- is possible.
 //   map overload:    offsets minD .. minD + numD - 2, strictly smallest value wins (left map); the right map is never
 //                    assigned by the reference and comes out as zeros
 //   volume overload: offsets minD .. minD + numD - 1, float slices normalised with cv::normalize(NORM_MINMAX)

@@ -260,7 +260,10 @@ int mdisp_legacy_disparity(mdisp_ctx*, const mdisp_image* left, const mdisp_imag
  *        it is all zeros.
  *   cost (host floats numDisparity x rows x cols, or NULL): the cost-volume overload, every offset, every slice
  *        normalised to [0, 1] (cv::normalize NORM_MINMAX), for both map types.
- * An even winSize or a size mismatch fails with MDISP_E_BADARG (the reference returns an empty result). */
+ * An even winSize or a size mismatch fails with MDISP_E_BADARG (the reference returns an empty result).
+ * Parity unpinned: sums follow a CPU restatement (row-major over the window, float products, double sums); the library
+ * routines the reference calls may round differently in the last bit, which can flip the strict '<' between near-equal
+ * scores. */
 int mdisp_ncc(mdisp_ctx*, const mdisp_image* left, const mdisp_image* right, int is_left, int winSize, int minDisparity,
               int numDisparity, mdisp_image* out, float* cost);
 

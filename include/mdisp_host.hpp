@@ -14,6 +14,7 @@
 #define MDISP_HOST_HPP
 
 #include <cstdint>
+#include <atomic>
 #include <cstring>
 #include <iostream>
 #include <memory>
@@ -146,16 +147,43 @@ template <class M> M censusStereo(StereoMatchParamT<M> param, CENSUS_ALGORITHM m
                                                    mdisp_image* o) { return mdisp_census_stereo(c, l, r, p, (int)method, agg, o); });
 }
 
+// The reference's asw_gifs aggregates dense-SIFT descriptor slices (computeDisp_Feature(param, costs_ds, FEATURE_SIFT),
+// methods_disp.cpp:1162), which this library does not compute.  A call in the reference's own six-argument form therefore
+// takes its slices from the source selected here: MDISP_COST_CENSUS (the default) or MDISP_COST_ABSDIFF.  While the
+// choice has never been made explicitly, the first such call prints one note on std::cout, so that swapping the include
+// cannot change results silently; callers that hold the SIFT slices pass them with MDISP_COST_VOLUME instead.
+namespace detail {
+inline std::atomic<int>& asw_source_word() { static std::atomic<int> w(-1); return w; }      // -1: never chosen
+}
+inline void set_asw_cost_source(int cost_source) { detail::asw_source_word().store(cost_source); }
+inline int asw_cost_source()
+{
+    const int v = detail::asw_source_word().load();
+    return v < 0 ? MDISP_COST_CENSUS : v;
+}
+inline int asw_cost_source_for_reference_call()
+{
+    static std::atomic<bool> told(false);
+    if (detail::asw_source_word().load() < 0 && !told.exchange(true))
+        std::cout << "asw_gifs: cost slices come from the GPU census-Hamming cost, not from dense SIFT descriptors "
+                     "(methods_disp.cpp:1162 is not built); choose with mdisp::set_asw_cost_source() or pass the slices (MDISP_COST_VOLUME)"
+                  << std::endl;
+    return asw_cost_source();
+}
+
 // methods_disp.h:66 -> CV_32F disparity.  cost_source selects what stands in for the dense-SIFT
 // slices of computeDisp_Feature; with MDISP_COST_VOLUME the caller passes those slices.
-template <class M> M asw_gifs(StereoMatchParamT<M> param, double eps, GIF_TYPE gifType = GIF, int r2 = 5, double namda = 0.1,
-                              double h = 0.5, int cost_source = MDISP_COST_CENSUS, const float* costs = nullptr)
+template <class M> M asw_gifs(StereoMatchParamT<M> param, double eps, GIF_TYPE gifType, int r2, double namda,
+                              double h, int cost_source, const float* costs = nullptr)
 {
     return detail::pair_call(param, MDISP_32F, [&](mdisp_ctx* c, const mdisp_image* l, const mdisp_image* r, const mdisp_param* p,
                                                    mdisp_image* o) {
         return mdisp_asw_gifs(c, l, r, p, eps, (int)gifType, r2, namda, h, cost_source, costs, o);
     });
 }
+// the reference's own form (methods_disp.h:66): the slice source is the process-wide choice above
+template <class M> M asw_gifs(StereoMatchParamT<M> param, double eps, GIF_TYPE gifType = GIF, int r2 = 5, double namda = 0.1, double h = 0.5)
+{ return asw_gifs(param, eps, gifType, r2, namda, h, asw_cost_source_for_reference_call(), nullptr); }
 
 // ximgproc::fastGlobalSmootherFilter(guide, src, dst, lambda, sigma_color, lambda_attenuation, num_iter); dst gets src's type
 template <class M> void fastGlobalSmootherFilter(M guide, M src, M& dst, double lambda, double sigma_color, double lambda_attenuation = 0.25,

@@ -46,7 +46,15 @@ int main(int argc, char** argv)
     Mat cen;
     countCensusImg(L, cen);
     // the call the reference's main() makes (cameraCalibration.cpp:174), with census costs in place of dense SIFT
-    Mat dOurs = asw_gifs(p, 0.01, OURS_GIF3, 15, 0.01, 0.5);       // CV_32F
+    Mat dOurs = asw_gifs(p, 0.01, OURS_GIF3, 15, 0.01, 0.5);       // CV_32F; prints the cost-source note (first call, source never chosen)
+    {
+        Mat again = asw_gifs(p, 0.01, OURS_GIF3, 15, 0.01, 0.5);   // no second note
+        set_asw_cost_source(MDISP_COST_CENSUS);                    // explicit choice: same slices, and no note from now on
+        Mat chosen = asw_gifs(p, 0.01, OURS_GIF3, 15, 0.01, 0.5);
+        if (again.empty() || chosen.empty() || std::memcmp(again.data(), dOurs.data(), (size_t)H * W * 4) ||
+            std::memcmp(chosen.data(), dOurs.data(), (size_t)H * W * 4))
+            return fail("asw_gifs: repeated calls differ");
+    }
     if (dCensus.empty() || dSad.empty() || d16.empty() || cen.empty() || dOurs.empty()) return fail("empty output");
     FILE* f = std::fopen(argv[5], "wb");
     if (!f) return fail("open output");

@@ -53,6 +53,8 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     out = tmp_path / "host.bin"
     r = subprocess.run([_exe(), "gpu", str(H), str(W), str(maxD), str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the reference's six-argument asw_gifs stands on dense-SIFT slices; the drop-in says once where its slices come from
+    assert r.stdout.count("asw_gifs: cost slices come from the GPU census-Hamming cost") == 1
     buf = np.fromfile(out, dtype=np.uint8)
     n = H * W
     o = 0
