@@ -465,6 +465,366 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
     finish();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same sweep without a workgroup barrier per step (headline geometry: 16 lanes x 16 disparities, 256 compute lanes,
+// byte sums, no masked disparities, eight paths; first and second sweep).
+//
+// A wave holds four neighbouring rows.  Three of the four hand-offs between neighbouring rows therefore stay inside one
+// wave: the anti-diagonal and the vertical state move from lanes 16k .. 16k+15 to the next sixteen lanes through the
+// cross-lane network (ds_bpermute_b32: no LDS memory access, no synchronisation -- it is the wave's own instruction
+// stream), right after they are produced; the diagonal state, which is consumed two steps later, waits one step in an
+// LDS row that only its own wave reads (LDS operations of one wave execute in order).  Only the hand-off from a wave's
+// last row to the next wave's first row crosses waves.  It goes through a ring of RING pixels in LDS per link with two
+// counters (pixels published, pixels released): the producer may run up to RING - 3 steps ahead of the minimum distance,
+// so the waves of a workgroup no longer wait for the slowest of them in every step -- a wave waits only when its ring is
+// empty or full.  The communication wave is the producer of wave 0's ring and the consumer of wave 3's; it moves up to
+// four pixels per memory round trip in each direction and never blocks on one side while the other can progress.
+// Every wait is bounded (HANDOFF_TIMEOUT_TICKS) and ends in the sticky error word.
+constexpr int SGM3_RING = 8;
+struct RingLds {
+    u32 ring[5][SGM3_RING][3][64];    // link k: [pixel % RING][anti-diagonal, vertical, diagonal][16 lanes x 4 dwords]
+    u32 stD[2][16][64];               // [step parity][row][...]: the diagonal state on its way to the next row of the same wave
+    int prod[5], cons[5];             // per link: pixels published by the producer / released by the consumer
+};
+
+// polls an LDS counter until it reaches `need`; wave-uniform.  Returns the value seen, or a huge one after a timeout
+// (the error word is set and the caller's later waits fall through).
+// (The counters are addressed through LDS-typed pointers: through a generic pointer the accesses become flat operations,
+// whose waits also drain the global loads in flight.)
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int lds_peek(const int* word) { return __builtin_amdgcn_readfirstlane(*(const volatile lds_int*)word); }
+__device__ __forceinline__ void lds_poke(int* word, int value) { *(volatile lds_int*)word = value; }
+__device__ __forceinline__ int ring_wait(const int* word, int need, int* err)
+{
+    unsigned long long t0 = 0;
+    int v;
+    for (int it = 0;; it++) {
+        v = lds_peek(word);
+        if (v >= need) break;
+        if ((it & 255) == 255) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > HANDOFF_TIMEOUT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = 0x3FFFFFFF;
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void ring_post(int* word, int value)      // after the data it covers (same wave: LDS operations stay in order)
+{
+    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) lds_poke(word, value);
+    asm volatile("" ::: "memory");
+}
+
+template <bool UP, int ROLE, bool COH>
+__device__ __forceinline__ void sgm3_ring_body(const RowArgs& ra, const int band, const int pair, RingLds& sh, u32 (*srow)[16 * 8],
+                                               const u32 (*exclMask)[8])
+{
+    constexpr int LPC = 16, NRT = 8, NT = 256, SLOTS = 16, DPLn = 16, DP = 256, NW = 4, SWN = 4, R = SGM3_RING;
+    constexpr bool SECOND = ROLE != 0;
+    static_assert(ROLE == 0 || ROLE == 1, "first or second sweep");
+    const Sgm2Args& a = ra.a;
+    auto finish = [&]() {
+        if constexpr (COH && ROLE == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_store(ra.done + ((size_t)((UP ? ra.batch : 0) + pair) * ra.nb + band), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    const int H = a.H, W = a.W;
+    u8* hand = ra.hand + (size_t)pair * ra.strideHand;
+    const bool hasPrev = band > 0, hasNext = band + 1 < ra.nb;
+    auto lds_get = [&](const u32* p, u32 (&w)[SWN]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    };
+    auto lds_put = [&](u32* p, const u32 (&w)[SWN]) { *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]); };
+
+    if (threadIdx.x >= NT) {
+        // ---- communication wave: lanes 0..47 = three states x sixteen lanes of one pixel per memory operation
+        const int lane = threadIdx.x - NT, which = lane / LPC, lic = lane % LPC;
+        const bool mine = which < 3;
+        int* progMe = ra.sync + 16 + ((size_t)((UP ? ra.batch : 0) + pair) * ra.nb + band);
+        const int* progNb = progMe - 1;
+        const __amdgpu_buffer_rsrc_t rsrc = hand_rsrc(hand, ra.strideHand);
+        constexpr u32 DPB = 256;
+        auto hand_slot = [&](int bnd, int u) -> u32 { return (u32)((((size_t)(bnd & ra.ringMask) * W + u) * 3 + which) * DPB + lic * 16); };
+        if (lane == 0) {
+            if (!hasPrev) lds_poke(&sh.prod[0], 0x3FFFFFFF);       // nothing to wait for: the first row's paths start afresh
+            if (!hasNext) lds_poke(&sh.cons[4], 0x3FFFFFFF);       // nobody reads the last row's states
+        }
+        constexpr int KB = 4;                   // pixels per memory round trip, each way
+        u32 w[KB][SWN];
+#pragma unroll
+        for (int q = 0; q < KB; q++)
+#pragma unroll
+            for (int e = 0; e < SWN; e++) w[q][e] = 0;
+        int parked = 0, inflight = 0, sent = 0, announced = 0, seen = hasPrev ? 0 : W;
+#if defined(SGM3_RING_KNOCK) && (SGM3_RING_KNOCK & 1)
+        // timing experiment (results wrong): no dependency between bands
+        if (lane == 0) { lds_poke(&sh.prod[0], 0x3FFFFFFF); lds_poke(&sh.cons[4], 0x3FFFFFFF); }
+        const int wantIn = 0, wantOut = 0;
+#else
+        const int wantIn = hasPrev ? W : 0, wantOut = hasNext ? W : 0;
+#endif
+        unsigned long long t0 = 0;
+        int idle = 0;
+        while (parked < wantIn || sent < wantOut) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the loads of the previous round have arrived, its stores have completed
+            if (sent > announced) {
+                if (lane == 0) __hip_atomic_store(progMe, sent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                announced = sent;
+            }
+            bool moved = false;
+            if (inflight > 0) {
+#pragma unroll
+                for (int q = 0; q < KB; q++)
+                    if (q < inflight && mine) lds_put(&sh.ring[0][(parked + q) % R][which][lic * 4], w[q]);
+                parked += inflight;
+                inflight = 0;
+                ring_post(&sh.prod[0], parked);
+                moved = true;
+            }
+            if (parked < wantIn) {
+                if (seen < W) seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                const int released = lds_peek(&sh.cons[0]);
+                // pixel p may be fetched once the band above has published it (plus the configured slack) and its ring entry is free
+                const int avail = seen >= W ? W : seen - ra.slack;
+                const int n = min(KB, min(min(avail, released + R), W) - parked);
+                if (n > 0) {
+#pragma unroll
+                    for (int q = 0; q < KB; q++)
+                        if (q < n && mine) {
+                            const uint4 v = hand_load16(rsrc, hand_slot(band - 1, parked + q));
+                            w[q][0] = v.x; w[q][1] = v.y; w[q][2] = v.z; w[q][3] = v.w;
+                        }
+                    inflight = n;
+                    moved = true;
+                }
+            }
+            if (sent < wantOut) {
+                const int ready = lds_peek(&sh.prod[4]);
+                asm volatile("" ::: "memory");
+                const int n = min(KB, min(ready, W) - sent);
+                if (n > 0) {
+#pragma unroll
+                    for (int q = 0; q < KB; q++)
+                        if (q < n && mine)
+                            hand_store16(rsrc, hand_slot(band, sent + q), *reinterpret_cast<const uint4*>(&sh.ring[4][(sent + q) % R][which][lic * 4]));
+                    sent += n;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ring entries have been read
+                    ring_post(&sh.cons[4], sent);
+                    moved = true;
+                }
+            }
+            if (!moved) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++idle & 255) == 0) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > HANDOFF_TIMEOUT_TICKS || __hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(ra.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) {       // let the compute waves run to their end
+                            lds_poke(&sh.prod[0], 0x3FFFFFFF);
+                            lds_poke(&sh.cons[4], 0x3FFFFFFF);
+                        }
+                        break;
+                    }
+                }
+            } else { idle = 0; t0 = 0; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (hasNext && lane == 0) __hip_atomic_store(progMe, W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finish();
+        return;
+    }
+
+    // ---- compute waves ----
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave 0..3: consumes link wv, produces link wv + 1
+    const int lic = threadIdx.x % LPC, j = threadIdx.x / LPC, l = j & 3;
+    const int T = W + 6;                                   // wave-local steps: row l of the wave works on u = t - 2l
+    const int v = band * SLOTS + j - ra.vofs;
+    const bool rowOk = v >= 0 && v < H;
+    const int vc = min(max(v, 0), H - 1);
+    const int y = UP ? H - 1 - vc : vc;
+    const bool top = v == 0;
+    const int vFirst = band * SLOTS - ra.vofs, vLastC = min(max(vFirst + SLOTS - 1, 0), H - 1), vFirstC = min(max(vFirst, 0), H - 1);
+    const int yLo = UP ? H - 1 - vLastC : vFirstC;
+    const u32 dy = (u32)(y - yLo);
+    const u8* const cLbase = a.cL + (size_t)pair * a.strideL + (size_t)yLo * a.pL;
+    const u8* const cRbase = a.cR + (size_t)pair * a.strideR + (size_t)yLo * a.pR - DP;
+    constexpr u32 SB = DP;
+    u8* const Sbase = reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS) + (size_t)yLo * W * SB;
+    uint2* const recBase = a.rec + (size_t)pair * a.strideRec + (size_t)yLo * W;
+    const u32 cLoff = dy * (u32)a.pL;
+    const u32 cRoff = dy * (u32)a.pR + (u32)(DP + a.maxD - a.minD - lic * DPLn - (DPLn - 1));
+    const u32 Soff = dy * (u32)W * SB + (u32)lic * 16;
+    const u32 recOff = dy * (u32)W;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<u8*>(a.S + (size_t)pair * a.strideS), 0,
+                                                                           (int)(a.strideS * sizeof(u16)), 0x00020000);
+    const u32 sRowBase = (u32)yLo * (u32)W * SB;
+    auto s4_load = [&](u32 off) -> uint4 {
+        if constexpr (COH) {
+            const md_v4u d = __builtin_amdgcn_raw_buffer_load_b128(srsrc, (int)off, (int)sRowBase, 18);
+            return make_uint4(d.x, d.y, d.z, d.w);
+        } else return load16_stream(Sbase + off);
+    };
+    auto s4_store = [&](u32 off, const uint4& val) {
+        if constexpr (COH) {
+            md_v4u d = {val.x, val.y, val.z, val.w};
+            __builtin_amdgcn_raw_buffer_store_b128(d, srsrc, (int)off, (int)sRowBase, 18);
+        } else store16_stream(Sbase + off, val);
+    };
+    u32 tail[NRT];
+#pragma unroll
+    for (int q = 0; q < NRT; q++) tail[q] = 0;
+    const u32 P1P1 = a.P1P1, P2P2 = a.P2P2;
+    auto fresh = [&](u32 (&N)[NRT]) {
+#pragma unroll
+        for (int q = 0; q < NRT; q++) N[q] = 0u;
+    };
+    // cross-lane source of the row above inside the wave: lane - 16 (the first row's lanes read themselves and are overwritten)
+    const int upLane = (int)(((threadIdx.x & 63) >= 16 ? (threadIdx.x & 63) - 16 : (threadIdx.x & 63)) * 4);
+    auto from_above = [&](const u32 (&src)[SWN], u32 (&dst)[SWN]) {
+#pragma unroll
+        for (int q = 0; q < SWN; q++) dst[q] = (u32)__builtin_amdgcn_ds_bpermute(upLane, (int)src[q]);
+    };
+    const bool firstRow = l == 0, lastRow = l == 3;
+    u32* const ringIn = &sh.ring[0][0][0][0] + (size_t)wv * (R * 3 * 64) + lic * 4;         // this wave's incoming link
+    u32* const ringOut = &sh.ring[0][0][0][0] + (size_t)(wv + 1) * (R * 3 * 64) + lic * 4;  // its outgoing link
+    u32* const stDown = &sh.stD[0][j][lic * 4];                                              // own row's diagonal state (parity 0)
+    const u32* const stUp = &sh.stD[0][j > 0 ? j - 1 : 0][lic * 4];                          // the row above's
+    constexpr int STD_PAR = 16 * 64;
+
+    u32 Nh[NRT];
+    EdgeRegs edge = {INF2, INF2};
+    u32 ooh = 0;
+    fresh(Nh);
+    u32 clw = 0, rbw[NW], sbw[NW];
+#pragma unroll
+    for (int q = 0; q < NW; q++) { rbw[q] = 0; sbw[q] = 0; }
+    int xf = 0;
+    auto fetch = [&](int t) {
+        const int u = min(max(t - 2 * l, 0), W - 1);
+        xf = UP ? W - 1 - u : u;
+        clw = *reinterpret_cast<const u32*>(cLbase + (cLoff + (u32)(xf & ~3)));
+        __builtin_memcpy(rbw, cRbase + (cRoff + (u32)xf), 2 * NRT);
+        if (SECOND) {
+            const uint4 v4 = s4_load(Soff + (u32)xf * DP);
+            sbw[0] = v4.x; sbw[1] = v4.y; sbw[2] = v4.z; sbw[3] = v4.w;
+        }
+    };
+    fetch(0);
+    u32 V0[SWN], V1[SWN], DA[SWN], DB[SWN], curA[SWN];
+#pragma unroll
+    for (int q = 0; q < SWN; q++) { V0[q] = 0; V1[q] = 0; DA[q] = 0; DB[q] = 0; curA[q] = 0; }
+    int seenProd = 0, seenCons = 0;
+#if defined(SGM3_RING_KNOCK) && (SGM3_RING_KNOCK & 2)
+    seenProd = 0x3FFFFFFF; seenCons = 0x3FFFFFFF;       // timing experiment (results wrong): the waves never wait for each other
+#endif
+    // the first row of the wave takes what a step "-1" and "-2" would have fetched: the vertical and diagonal state of pixel 0,
+    // the anti-diagonal and vertical state of pixel 1
+    if (seenProd < min(2, W)) seenProd = ring_wait(&sh.prod[wv], min(2, W), ra.err);
+    if (firstRow) {
+        lds_get(ringIn + 1 * 64, V0);
+        lds_get(ringIn + 2 * 64, DB);
+        lds_get(ringIn + (1 % R) * 192, curA);
+        lds_get(ringIn + (1 % R) * 192 + 64, V1);
+    }
+    auto step = [&](int t, auto parc, u32 (&Vuse)[SWN], u32 (&D)[SWN]) {
+        constexpr int PAR = decltype(parc)::value;
+        const int u = t - 2 * l;
+        const bool active = rowOk && u >= 0 && u < W;
+        const int x = xf;
+        u32 C[NRT], L[NRT], Sacc[NRT];
+        cost_n<NRT>(census_byte(clw, x), rbw, C);
+        if (SECOND) unpack_n<NRT>(sbw, Sacc);
+        fetch(t + 1);
+        // the last row publishes pixel u3 in this step: its ring entry must have been released
+        const int u3 = t - 6;
+        const bool publish = u3 >= 0 && u3 < W;
+        if (publish && u3 >= seenCons + R) seenCons = ring_wait(&sh.cons[wv + 1], u3 - R + 1, ra.err);
+        u32* const outEntry = ringOut + (u3 & (R - 1)) * 192;
+        const bool firstCol = u == 0, lastCol = u == W - 1;
+        if (__any(top || firstCol || lastCol)) {
+#pragma unroll
+            for (int q = 0; q < SWN; q++) {
+                if (top || lastCol) curA[q] = 0;
+                if (top) Vuse[q] = 0;
+                if (top || firstCol) D[q] = 0;
+            }
+            if (firstCol) { fresh(Nh); ooh = 0; }
+        }
+        step_lazy_n<LPC, NRT>(Nh, ooh, C, P1P1, P2P2, L, lic, edge);
+#pragma unroll
+        for (int q = 0; q < NRT; q++) Sacc[q] = SECOND ? pkadd(Sacc[q], L[q]) : L[q];
+        u32 N[NRT], ow[SWN];
+        // anti-diagonal: consumed at once by the row below
+        unpack_n<NRT>(curA, N);
+        step_pack_n<false, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic, edge);
+#pragma unroll
+        for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+        if (lastRow && publish) lds_put(outEntry, ow);
+        from_above(ow, curA);
+        // vertical: the row below uses it two steps from now, out of the register set this step has just consumed
+        unpack_n<NRT>(Vuse, N);
+        step_pack_n<false, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic, edge);
+#pragma unroll
+        for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+        if (lastRow && publish) lds_put(outEntry + 64, ow);
+        from_above(ow, Vuse);
+        // diagonal: three steps from now; it spends one of them in the wave's own LDS row
+        unpack_n<NRT>(D, N);
+        step_pack_n<false, LPC, NRT>(N, C, P1P1, P2P2, tail, L, ow, lic, edge);
+#pragma unroll
+        for (int q = 0; q < NRT; q++) Sacc[q] = pkadd(Sacc[q], L[q]);
+        if (lastRow && publish) lds_put(outEntry + 128, ow);
+        lds_put(stDown + PAR * STD_PAR, ow);
+        if (publish) ring_post(&sh.prod[wv + 1], u3 + 1);
+        if (!SECOND) {
+            u32 sw4[NW];
+            pack_n<NRT>(Sacc, sw4);
+            if constexpr (COH) {
+                s4_store(!active ? 0xFFFFFFF0u : Soff + (u32)x * DP, make_uint4(sw4[0], sw4[1], sw4[2], sw4[3]));
+            } else if (active) {
+                s4_store(Soff + (u32)x * DP, make_uint4(sw4[0], sw4[1], sw4[2], sw4[3]));
+            }
+        } else {
+            wta_n<false, LPC, NRT>(a, Sacc, tail, lic, &srow[j][0], exclMask, recBase + (recOff + (u32)x), active);
+        }
+        // what the next steps consume from the row above
+        lds_get(stUp + (PAR ^ 1) * STD_PAR, D);
+        {
+            const int need = min(t + 3, W);
+            if (seenProd < need) seenProd = ring_wait(&sh.prod[wv], need, ra.err);
+            if (firstRow) {
+                const u32* const e2 = ringIn + ((t + 2) & (R - 1)) * 192;
+                lds_get(e2, curA);
+                lds_get(e2 + 64, Vuse);
+                lds_get(ringIn + ((t + 1) & (R - 1)) * 192 + 128, D);
+            }
+            // (LDS operations of a wave are performed in order: the counter is written after the reads above have been done)
+            ring_post(&sh.cons[wv], t + 2);
+        }
+    };
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 2 <= T; t += 2) {
+        step(t, P0{}, V0, DA);
+        step(t + 1, P1{}, V1, DB);
+    }
+    if (t < T) step(t, P0{}, V0, DA);
+    finish();
+}
+
 // One sweep (one direction, one role) over a range of bands: the launch counts tickets on its own word.
 template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16 = false, bool FOUR = false>
 __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S16, ROLE)) void sgm3_rows_kernel(RowArgs ra)
@@ -548,6 +908,47 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, 
 #ifdef SGM3_TRACE
     if (threadIdx.x == 0 && ticket < SGM3_TRACE_MAX) { g_trace[ticket][2] = __builtin_amdgcn_s_memrealtime(); g_trace[ticket][5] = __builtin_amdgcn_s_memtime(); }
 #endif
+}
+
+// The one-launch schedule on the barrier-free sweep body (sgm3_ring_body): same tickets, same waits between the two
+// directions.  48 KB of LDS per workgroup: three workgroups per CU.
+__global__ __launch_bounds__(256 + 64, 4) void sgm3_meet_ring_kernel(RowArgs ra)
+{
+    __shared__ RingLds sh;
+    __shared__ u32 srow[16][16 * 8];
+    __shared__ u32 exclMask[16 + 3][8];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ra.sync[ra.ticket], 1);
+    if (threadIdx.x < 5) { sh.prod[threadIdx.x] = 0; sh.cons[threadIdx.x] = 0; }
+    init_excl_mask_n<8>(exclMask);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    const int perStep = 2 * ra.batch, band = ticket / perStep, r = ticket - band * perStep;
+    const bool up = (r >= ra.batch) != (ra.firstUp > ra.firstDown);
+    const int pair = r >= ra.batch ? r - ra.batch : r;
+    const bool second = band >= (up ? ra.firstUp : ra.firstDown);
+    if (second) {
+        if (threadIdx.x == 0) {
+            const int* flag = ra.done + ((size_t)((up ? 0 : ra.batch) + pair) * ra.nb + (ra.nb - 1 - band));
+            unsigned long long t0 = 0;
+            for (int it = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; it++) {
+                if ((it & 63) == 63) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > HANDOFF_TIMEOUT_TICKS) { __hip_atomic_store(ra.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (__hip_atomic_load(ra.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
+    RowArgs rl = ra;
+    if (up) { rl.hand = ra.handUp; rl.vofs = ra.vofsUp; }
+    if (!up && !second) sgm3_ring_body<false, 0, true>(rl, band, pair, sh, srow, exclMask);
+    else if (up && !second) sgm3_ring_body<true, 0, true>(rl, band, pair, sh, srow, exclMask);
+    else if (up) sgm3_ring_body<true, 1, true>(rl, band, pair, sh, srow, exclMask);
+    else sgm3_ring_body<false, 1, true>(rl, band, pair, sh, srow, exclMask);
 }
 
 template <int LPC, int NRT, int NT, bool BOTH, bool FOUR = false>
@@ -702,7 +1103,9 @@ int md_sgm3_meet(hipStream_t s, const Sgm2Args& a, u8* handDown, u8* handUp, siz
     MD_REQUIRE(strideHand < ((size_t)1 << 32), MDISP_E_RANGE, "row bands: hand-off ring of %zu bytes per pair exceeds 4 GB", strideHand);
     { const int sl = md_tune(MDISP_TUNE_SGM_BAND_SLACK); ra.slack = sl > 0 ? sl : 0; }
     const dim3 g((unsigned)(2 * ra.nb) * batch);
-    sgm3_meet_kernel<false, 16, 8, SGM3_NT16><<<g, SGM3_NT16 + 64, 0, s>>>(ra);
+    // the barrier-free variant is bit-exact but measured slower (0.92 against 0.75 ms per pair at 64 pairs): opt-in
+    if (SGM3_NT16 == 256 && md_tune(MDISP_TUNE_SGM_RING_HANDOFF) > 0) sgm3_meet_ring_kernel<<<g, 256 + 64, 0, s>>>(ra);
+    else sgm3_meet_kernel<false, 16, 8, SGM3_NT16><<<g, SGM3_NT16 + 64, 0, s>>>(ra);
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }

@@ -500,7 +500,8 @@ enum {
     MDISP_TUNE_SGM_MEET_MAX = 12,      /* row bands: largest batch whose two sweeps start from both image edges at once (default: any) */
     MDISP_TUNE_SGM_ONE_LAUNCH = 13,    /* row bands: 0 = the two sweep directions as two launches per phase, 1 = both directions and both roles in one launch; default: one launch up to 96 pairs */
     MDISP_TUNE_SAT_INT_TABLES = 14,    /* 1: mdisp_sad_inte and the stereomatch_1 _inteOpti matchers sum in exact integer tables instead of the reference's CV_32F ones */
-    MDISP_TUNE_COUNT = 15
+    MDISP_TUNE_SGM_RING_HANDOFF = 15,  /* row bands, one-launch schedule: 0 = one workgroup barrier per step (default), 1 = barrier-free waves with LDS rings between them (measured slower) */
+    MDISP_TUNE_COUNT = 16
 };
 int mdisp_tuning_set(int key, int value);
 int mdisp_tuning_get(int key);

@@ -272,6 +272,12 @@ BATCH_CASES = [
     (6, 70, 140, 140, 96, 0, 32, {}),                           # eight lanes per pixel, both edges
     (6, 75, 100, 100, 48, 3, 32, {}),                           # four lanes per pixel, both edges, masked tail
     (7, 80, 120, 120, 128, 0, 300, {"SGM_MEET_MAX": 0}),        # 16-bit path states, one sweep after the other
+    (9, 70, 150, 150, 256, 0, 32, {"SGM_RING_HANDOFF": 1}),     # one launch without the workgroup barrier per step: rows handed on inside a wave and through LDS rings between waves
+    (7, 100, 130, 130, 256, 0, 32, {"SGM_RING_HANDOFF": 1}),
+    (7, 128, 130, 130, 256, 0, 32, {"SGM_RING_HANDOFF": 1, "SGM_HAND_RING": 2}),
+    (5, 37, 5, 8, 256, 0, 32, {"SGM_RING_HANDOFF": 1}),         # ... rows shorter than the ring between two waves
+    (5, 52, 9, 12, 256, 0, 32, {"SGM_RING_HANDOFF": 1}),
+    (5, 37, 5, 8, 256, 0, 32, {}),
 ]
 BATCH5_CASES = [
     (6, 70, 150, 150, 256, 0, 32), (6, 60, 140, 140, 100, 2, 32), (5, 50, 90, 90, 48, 0, 60), (6, 64, 120, 120, 128, 0, 300), (1, 40, 100, 100, 64, 0, 400),
@@ -489,7 +495,7 @@ def test_sgm_full_size_frame_bit_exact(api, orc, sgm_schedule):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tuning", [{}, {"SGM_ONE_LAUNCH": 0}])
+@pytest.mark.parametrize("tuning", [{}, {"SGM_ONE_LAUNCH": 0}, {"SGM_RING_HANDOFF": 1}])
 def test_sgm_batch_full_size_fills_the_gpu(api, orc, tuning):
     """A batch of full-size frames that occupies every workgroup slot several times over (the one-launch schedule hands
     four-path sums between workgroups of one launch, on whatever part of the chip they run): every pair equals the oracle
