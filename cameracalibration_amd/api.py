@@ -274,6 +274,39 @@ def sgbm_compute_batch(lefts, rights, params, chunk=0, ctx=None):
     return out
 
 
+MULTI_PIN_HOST = 1
+
+
+def sgbm_compute_batch_multi(devices, lefts, rights, params, chunk=0, pin_host=True):
+    """mdisp_sgbm_batch_multi: the pairs of a host batch spread over `devices` (HIP device indices, repeats allowed), one
+    host thread and one context per entry -> int16 N x H x W."""
+    Ls = [np.ascontiguousarray(a, dtype=np.uint8) for a in lefts]
+    Rs = [np.ascontiguousarray(a, dtype=np.uint8) for a in rights]
+    n = len(Ls)
+    if n != len(Rs):
+        raise ValueError("left / right count mismatch")
+    if n == 0:
+        return np.empty((0, 0, 0), np.int16)
+    H, W = Ls[0].shape
+    out = np.empty((n, H, W), dtype=np.int16)
+    ptrs = C.c_void_p * n
+    pl = ptrs(*[a.ctypes.data for a in Ls])
+    pr = ptrs(*[a.ctypes.data for a in Rs])
+    po = ptrs(*[out[i].ctypes.data for i in range(n)])
+    dev = (C.c_int * len(devices))(*devices)
+    check(load().mdisp_sgbm_batch_multi(dev, len(devices), pl, pr, n, H, W, W, C.byref(params), po, chunk, MULTI_PIN_HOST if pin_host else 0))
+    return out
+
+
+def sgbm_compute_rows_multi(devices, srcLeft, srcRight, params):
+    """mdisp_sgbm_rows_multi: one pair, its rows spread over `devices` -> CV_16S disparity x16."""
+    L, R = _u8(srcLeft), _u8(srcRight)
+    out = np.empty(L.shape[:2], dtype=np.int16)
+    dev = (C.c_int * len(devices))(*devices)
+    check(load().mdisp_sgbm_rows_multi(dev, len(devices), C.byref(image(L)), C.byref(image(R)), C.byref(params), C.byref(image(out))))
+    return out
+
+
 def sgbm_volume(srcLeft, srcRight, params, ctx=None):
     """Aggregated SGM cost volume S (uint16, H x W x numDisparities, biased by +P2 per path)."""
     L, R = _u8(srcLeft), _u8(srcRight)

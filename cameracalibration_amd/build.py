@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmdisp.so")
-SOURCES = ["api.hip", "census.hip", "sgm.hip", "sgm2.hip", "sgm3.hip", "sgbm_bt.hip", "bm.hip", "fgs.hip", "legacy.hip", "ncc.hip", "stereo.hip", "filters.hip", "gif_mc.hip", "host.hip"]
+SOURCES = ["api.hip", "census.hip", "sgm.hip", "sgm2.hip", "sgm3.hip", "sgbm_bt.hip", "bm.hip", "fgs.hip", "legacy.hip", "ncc.hip", "stereo.hip", "filters.hip", "gif_mc.hip", "host.hip", "multi.hip"]
 
 
 def _stale():

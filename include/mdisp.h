@@ -402,6 +402,26 @@ int mdisp_sgbm_rows_sweep_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* 
                               const mdisp_sgbm_params* p, int row_begin, int row_end, int direction, int second,
                               const void* d_boundary_in, void* d_boundary_out, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
 
+/* ---- several GPUs from one process (host-side; no counterpart in the reference, whose only concurrency is the two
+ * std::async calls of cameraCalibration.cpp:163-190).  One host thread and one context per entry of devices[]; an
+ * entry may repeat (several workers on one GPU).  No collective: pairs are independent, and the rows of one pair hand
+ * their boundary states from neighbour to neighbour. ----
+ *
+ * mdisp_sgbm_batch_multi: mdisp_sgbm_batch over devices[]: worker r takes a contiguous block of the pairs (blocks differ
+ * by at most one pair) and runs the chunked, double-buffered host batch on its device.  flags & MDISP_MULTI_PIN_HOST:
+ * the images and maps of the call are page-locked (hipHostRegister) while it runs, so uploads and downloads are DMA
+ * transfers that overlap the kernels.  Maps equal mdisp_sgbm_batch's bit for bit.
+ * mdisp_sgbm_rows_multi: ONE pair (CV_8UC1 views, CV_16SC1 map), its rows spread over devices[] in whole bands
+ * (mdisp_sgbm_rows_geometry): every worker holds both views, runs first the sweep whose boundary states arrive first,
+ * and delivers the states of its last row with hipMemcpyPeerAsync (a device copy when both workers share a GPU).
+ * The map equals mdisp_sgbm's bit for bit.  More workers than row bands: MDISP_E_BADARG. */
+enum { MDISP_MULTI_PIN_HOST = 1 };
+int mdisp_sgbm_batch_multi(const int* devices, int ndevices, const uint8_t* const* lefts, const uint8_t* const* rights, int npairs,
+                           int rows, int cols, size_t step_bytes, const mdisp_sgbm_params* p, int16_t* const* disps, int chunk,
+                           int flags);
+int mdisp_sgbm_rows_multi(const int* devices, int ndevices, const mdisp_image* left, const mdisp_image* right,
+                          const mdisp_sgbm_params* p, mdisp_image* out);
+
 /* census stereo on device buffers; d_disp: device double HxW */
 int mdisp_census_stereo_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, size_t pitch,
                             const mdisp_param* p, int census_method, int agg_mode, double* d_disp);

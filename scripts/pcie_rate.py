@@ -31,3 +31,13 @@ for chunk in (8, 16, 32):
     dt = (time.perf_counter() - t0) / N
     print(f"host-buffer mdisp_sgbm_batch, {N} pairs, chunk {chunk}: {dt*1e3:.2f} ms per pair, {H*W*D/dt/1e6:.0f} Mdisp/s "
           f"(pageable host memory, PCIe copies and sync included)")
+
+# the multi-device entry point with the host images page-locked for the call (one or two workers on this GPU)
+for devices, pin in (([0], False), ([0], True), ([0, 0], True)):
+    for chunk in (16, 32):
+        api.sgbm_compute_batch_multi(devices, Ls[:chunk], Rs[:chunk], p, chunk, pin_host=pin)
+        t0 = time.perf_counter()
+        out = api.sgbm_compute_batch_multi(devices, Ls, Rs, p, chunk, pin_host=pin)
+        dt = (time.perf_counter() - t0) / N
+        print(f"mdisp_sgbm_batch_multi, {len(devices)} worker(s), {'pinned' if pin else 'pageable'} host memory, chunk {chunk}: "
+              f"{dt*1e3:.2f} ms per pair, {H*W*D/dt/1e6:.0f} Mdisp/s (registration, PCIe copies and sync included)")

@@ -39,6 +39,23 @@ def test_no_device_fails_loudly_without_fallback():
     assert b"no CPU fallback" in lib.mdisp_last_error()
 
 
+def test_multi_device_entry_points_fail_loudly_without_a_device():
+    import numpy as np
+    from cameracalibration_amd import api
+    from cameracalibration_amd._lib import MdispError
+    lib = _lib.load()
+    if lib.mdisp_device_count() > 0:
+        return
+    img = np.zeros((32, 48), np.uint8)
+    par = api.sgbm_params(0, 16, 8, 32, 10, 1, 8, 1)
+    for call in (lambda: api.sgbm_compute_batch_multi([0], [img], [img], par), lambda: api.sgbm_compute_rows_multi([0], img, img, par)):
+        try:
+            call()
+            raise AssertionError("expected MDISP_E_NODEVICE")
+        except MdispError as e:
+            assert e.code == _lib.E_NODEVICE and "no CPU fallback" in str(e)
+
+
 def test_rectify_maps_and_synth_are_host_only():
     import numpy as np
     from cameracalibration_amd import api
