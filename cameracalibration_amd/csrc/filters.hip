@@ -75,6 +75,7 @@ __device__ __forceinline__ int raw_cost(const CostSrc& c, int x, int y, int k)
 // 256 columns x MM_ROWS rows and walks the slices with the tile's reference pixels in registers, so
 // each census / gray byte is fetched once and the shifted operand rows stay in cache.
 #define MM_ROWS 16
+#define MM_SLICES 4     // slices per workgroup (grid z): a tile's slices spread over several workgroups so that the launch fills the device
 __global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, int n, u32* __restrict__ part, int yBeg, int yEnd)
 {
     __shared__ u32 slo[4], shi[4];
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(CostSrc c, int k0, int
     int ref[MM_ROWS];
 #pragma unroll
     for (int j = 0; j < MM_ROWS; j++) ref[j] = (inx && j < rows) ? c.ref[(size_t)(y0 + j) * c.rp + x] : 0;
-    for (int k = 0; k < n; k++) {
+    const int kEnd = min(n, (int)(blockIdx.z + 1) * MM_SLICES);
+    for (int k = blockIdx.z * MM_SLICES; k < kEnd; k++) {
         int lo = 0x7FFFFFFF, hi = -1;
         if (inx) {
             const u8* p = c.pad + (size_t)y0 * c.pp + x + c.off0 + (k0 + k) * c.offStep;
@@ -690,16 +692,21 @@ static int dual_box_march(hipStream_t s, int n, int H, int W, int ksz, int mode,
 // 785-786: sigmaColor 2, sigmaSpace 3) fused with the final a*G + b (:667, 723, 802) and the
 // optional beta = a/(1-a) (:792).  Footprint = the taps within `radius` of the centre, visited in
 // row-major order with float accumulation like the library's scalar loop; BORDER_REFLECT_101.
-// The library interpolates the colour weight from a 4096-bin table of exp(); this kernel
-// evaluates the exponential directly (difference below 1e-6 of the weight).
+// The library interpolates the colour weight from a 4096-bin table of exp(); this kernel evaluates the exponential
+// directly (difference below 1e-6 of the weight) -- on this hardware the table's two gathers and its interpolation cost
+// more instructions than v_exp_f32 does.  What a tap costs is instructions, so the arithmetic is arranged for few of them:
+// the tile holds the planes scaled by s = sqrt(0.5 / sigmaColor^2 * log2 e), so that (p' - c')^2 is the exponent without
+// a multiply; the space weight enters as log2(w_s) in the same fused multiply-add, weight = exp2(-(p' - c')^2 + log2 w_s);
+// the weighted sum is a fused multiply-add as well; the quotient is scaled back by 1 / s at the end.  Per tap and pair
+// of planes: one subtraction, two fused multiply-adds, one addition (packed fp32) and two exponentials.
 #define BIL_X 32
 #define BIL_Y 16
 struct BilArgs {
     const float* A; const float* B; size_t N;
     int H, W, R, ntaps, yA, yB;
-    const int2* taps;        // {offset in the (a,b) tile, bits of the float space weight}
+    const int2* taps;        // {offset in the (a,b) tile, bits of log2 of the float space weight}
     const float* G; float* V; float* beta;
-    float colorK;            // -0.5/sigmaColor^2 * log2(e)
+    float colorS;            // sqrt(0.5/sigmaColor^2 * log2(e))
 };
 __global__ __launch_bounds__(256) void bilateral_ab_kernel(BilArgs a)
 {
@@ -708,32 +715,33 @@ __global__ __launch_bounds__(256) void bilateral_ab_kernel(BilArgs a)
     const int x0 = blockIdx.x * BIL_X, y0 = a.yA + blockIdx.y * BIL_Y, k = blockIdx.z;
     const float* A = a.A + (size_t)k * a.N;
     const float* B = a.B + (size_t)k * a.N;
+    const float S = a.colorS;
     for (int i = threadIdx.x; i < TW * TH; i += 256) {
         const int ty = i / TW, tx = i - ty * TW;
         const size_t src = (size_t)r101(y0 + ty - R, a.H) * a.W + r101(x0 + tx - R, a.W);
-        biltile[i] = make_float2(A[src], B[src]);
+        biltile[i] = make_float2(A[src] * S, B[src] * S);
     }
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // pixels (tx, ty) and (tx, ty + 8) of the tile
     const int c0 = (ty + R) * TW + tx + R, c1 = c0 + 8 * TW;
     // the a and b planes of a pixel travel as one packed pair: every step below is a packed fp32 instruction
-    // (v_pk_add / v_pk_mul; products and sums stay separate roundings, as in the library's scalar loop)
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2* tile2 = reinterpret_cast<const f2*>(biltile);
     const f2 v0 = tile2[c0], v1 = tile2[c1];
     f2 s0 = {0.0f, 0.0f}, w0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f}, w1 = {0.0f, 0.0f};
-    const float K = a.colorK;
     for (int t = 0; t < a.ntaps; t++) {
         const int2 tp = a.taps[t];
-        const float ws = __int_as_float(tp.y);
+        const float lw = __int_as_float(tp.y);
+        const f2 lws = {lw, lw};
         const f2 p = tile2[c0 + tp.x], q = tile2[c1 + tp.x];
-        f2 d = p - v0, e = q - v1;
-        d = d * d * K; e = e * e * K;
-        f2 w = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)}, u = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-        w = w * ws; u = u * ws;
-        s0 += p * w; w0 += w;
-        s1 += q * u; w1 += u;
+        const f2 d = p - v0, e = q - v1;
+        const f2 m = __builtin_elementwise_fma(-d, d, lws), n = __builtin_elementwise_fma(-e, e, lws);
+        const f2 w = {__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)}, u = {__builtin_amdgcn_exp2f(n.x), __builtin_amdgcn_exp2f(n.y)};
+        s0 = __builtin_elementwise_fma(p, w, s0); w0 += w;
+        s1 = __builtin_elementwise_fma(q, u, s1); w1 += u;
     }
+    const float inv = 1.0f / S;
+    s0 *= inv; s1 *= inv;
     const float sa0 = s0.x, sb0 = s0.y, wa0 = w0.x, wb0 = w0.y, sa1 = s1.x, sb1 = s1.y, wa1 = w1.x, wb1 = w1.y;
     const int x = x0 + tx;
     if (x >= a.W) return;
@@ -989,7 +997,7 @@ static int guide_prepare(mdisp_ctx* c, const u8* dGuide, size_t gpitch, int H, i
             for (int j = -R; j <= R; j++) {
                 const double rr = sqrt((double)i * i + (double)j * j);
                 if (rr > R) continue;
-                const float w = (float)exp(rr * rr * gsc);
+                const float w = (float)(rr * rr * gsc * 1.4426950408889634);      // log2 of the space weight exp(r^2 * gsc)
                 int2 t; t.x = i * TW + j; memcpy(&t.y, &w, 4);
                 taps.push_back(t);
             }
@@ -1090,7 +1098,7 @@ static int gif_filter_batch(mdisp_ctx* c, const GuideState& gs, GifScratch& sc, 
         BilArgs b;
         b.A = sc.F1; b.B = sc.F2; b.N = N; b.H = H; b.W = W; b.R = gs.bilR; b.ntaps = gs.bilN; b.yA = yA; b.yB = yB;
         b.taps = gs.bilTaps; b.G = gs.G; b.V = sc.F0; b.beta = beta;
-        b.colorK = (float)(-0.5 / (2.0 * 2.0) * 1.4426950408889634);
+        b.colorS = (float)sqrt(0.5 / (2.0 * 2.0) * 1.4426950408889634);
         const size_t lds = (size_t)(BIL_X + 2 * gs.bilR) * (BIL_Y + 2 * gs.bilR) * sizeof(float2);
         if (lds > 64 * 1024) { mdisp_set_error("bilateral radius %d is not supported", gs.bilR); return MDISP_E_UNSUPPORTED; }
         if (yB <= yA) return MDISP_OK;
@@ -1263,7 +1271,7 @@ int md_gif_band_stats(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpit
     for (int k0 = 0; k0 < D; k0 += n) {
         const int nb = D - k0 < n ? D - k0 : n;
         mm_init_kernel<<<(nb + 63) / 64, 64, 0, s>>>(sc.mm + 2, nb);
-        const dim3 gm((W + 255) / 256, (yB - yA + MM_ROWS - 1) / MM_ROWS);
+        const dim3 gm((W + 255) / 256, (yB - yA + MM_ROWS - 1) / MM_ROWS, (nb + MM_SLICES - 1) / MM_SLICES);
         u32* part = reinterpret_cast<u32*>(sc.T);
         cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part, yA, yB);
         cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
@@ -1327,7 +1335,7 @@ int md_gif_stereo(mdisp_ctx* c, void* scratch, const u8* dGuide, size_t gpitch, 
             MD_HIP(hipMemcpyAsync(sc.mm + 2, extDev + 2 * (size_t)k0, (size_t)nb * 8, hipMemcpyDeviceToDevice, s));
         } else {
             // per-workgroup partials go through the (otherwise idle) double scratch
-            const dim3 gm((W + 255) / 256, (H + MM_ROWS - 1) / MM_ROWS);
+            const dim3 gm((W + 255) / 256, (H + MM_ROWS - 1) / MM_ROWS, (nb + MM_SLICES - 1) / MM_SLICES);
             u32* part = reinterpret_cast<u32*>(sc.T);
             cost_minmax_kernel<<<gm, 256, 0, s>>>(cs, k0, nb, part, 0, H);
             cost_minmax_finish_kernel<<<nb, 256, 0, s>>>(part, (int)(gm.x * gm.y), nb, sc.mm + 2);
