@@ -65,7 +65,7 @@ EXPORTS = [
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
     "mdisp_context_device_bytes", "mdisp_sad_inte_mode",
     "mdisp_cost_sad_d", "mdisp_guided_filter_multi", "mdisp_adaptive_weight_guidedf",
-    "mdisp_sgbm_batch_multi", "mdisp_sgbm_rows_multi",
+    "mdisp_sgbm_batch_multi", "mdisp_sgbm_rows_multi", "mdisp_compute_similarity", "mdisp_adaptive_weight_guidedf_n",
 ]
 
 _lib = None
@@ -148,6 +148,8 @@ def load():
     lib.mdisp_last_kernel_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.mdisp_enable_timing.argtypes = [vp, C.c_int]
     lib.mdisp_context_device_bytes.argtypes = [vp]
+    lib.mdisp_compute_similarity.argtypes = [vp, img, img, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+    lib.mdisp_adaptive_weight_guidedf_n.argtypes = [vp, img, img, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, img]
     lib.mdisp_sgbm_batch_multi.argtypes = [P(C.c_int), C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, P(mdisp_sgbm_params), vp,
                                            C.c_int, C.c_int]
     lib.mdisp_sgbm_rows_multi.argtypes = [P(C.c_int), C.c_int, img, img, P(mdisp_sgbm_params), img]

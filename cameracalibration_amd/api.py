@@ -431,8 +431,12 @@ def stereoMatching(srcLeft, srcRight, algorithmType=SGBM, ctx=None):
         return getDisparity_BM(srcLeft, srcRight, ctx)
     if algorithmType == ADAPTIVE_WEIGHT_GUIDED_FILTER:
         return stereomatch_1.computeAdaptiveWeight_GuidedF(srcLeft, srcRight, DISPARITY_LEFT, 0.01, 15, 10, 150, ctx=ctx)   # :1801-1803
+    if algorithmType == ADAPTIVE_WEIGHT_GUIDED_FILTER_2:
+        return stereomatch_1.computeAdaptiveWeight_GuidedF_2(srcLeft, srcRight, DISPARITY_LEFT, 0.01, 13, 10, 150, ctx=ctx)  # :1804-1806
+    if algorithmType == ADAPTIVE_WEIGHT_GUIDED_FILTER_3:
+        return stereomatch_1.computeAdaptiveWeight_GuidedF_3(srcLeft, srcRight, DISPARITY_LEFT, 1e-6, 15, 0, 64, ctx=ctx)    # :1807-1809
     if algorithmType != SGBM:
-        raise NotImplementedError("only the BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER entries of stereoMatching are built")
+        raise NotImplementedError("only the BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER* entries of stereoMatching are built")
     return getDisparity_SGBM(srcLeft, srcRight, ctx)
 
 
@@ -629,6 +633,47 @@ DISPARITY_LEFT, DISPARITY_RIGHT = 0, 1          # methods/parametersStereo.h:5-9
 
 class stereomatch_1:
     """The reference's namespace of the same name: same function names, argument order and defaults."""
+
+    @staticmethod
+    def computeSimilarity(leftImg, rightImg, cost_d_imgs, regularity, thresC, thresG, dispType=DISPARITY_LEFT, winSize=None,
+                          minDisparity=0, numDisparity=30, ctx=None):
+        """Both overloads of computeSimilarity (methods/method_StereoMatching.h): `cost_d_imgs` (a list) is cleared and
+        receives numDisparity float32 slices -- bordered by winSize // 2 when a window is given (the ten-argument overload).
+        Left untouched for an even window, cleared only for mismatching sizes, as in the reference; inputs on which the
+        reference fails (gray views, DISPARITY_RIGHT) raise."""
+        L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+        if winSize is not None and winSize % 2 == 0:
+            return
+        del cost_d_imgs[:]
+        if L.shape != R.shape:
+            return
+        H, W = L.shape[:2]
+        b = 0 if winSize is None else winSize // 2
+        vol = np.empty((numDisparity, H + 2 * b, W + 2 * b), np.float32)
+        check(load().mdisp_compute_similarity(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), 1 if dispType == DISPARITY_LEFT else 0,
+                                              regularity, thresC, thresG, 0 if winSize is None else winSize, minDisparity, numDisparity,
+                                              vol.ctypes.data))
+        cost_d_imgs.extend(vol[k] for k in range(numDisparity))
+
+    @staticmethod
+    def _guidedf_n(which, leftImg, rightImg, dispType, eps, winSize, minDisparity, numDisparity, ctx):
+        L, R = np.ascontiguousarray(leftImg, np.uint8), np.ascontiguousarray(rightImg, np.uint8)
+        out = np.empty(L.shape[:2], np.float32)
+        check(load().mdisp_adaptive_weight_guidedf_n(_ctx(ctx), C.byref(image(L)), C.byref(image(R)), which, 1 if dispType == DISPARITY_LEFT else 0,
+                                                     eps, winSize, minDisparity, numDisparity, C.byref(image(out))))
+        return out
+
+    @staticmethod
+    def computeAdaptiveWeight_GuidedF_2(leftImg, rightImg, dispType=DISPARITY_LEFT, eps=0.01, winSize=35, minDisparity=186, numDisparity=144,
+                                        ctx=None):
+        """methods/method_StereoMatching.h:182-184."""
+        return stereomatch_1._guidedf_n(2, leftImg, rightImg, dispType, eps, winSize, minDisparity, numDisparity, ctx)
+
+    @staticmethod
+    def computeAdaptiveWeight_GuidedF_3(leftImg, rightImg, dispType=DISPARITY_LEFT, eps=1e-6, winSize=35, minDisparity=186, numDisparity=144,
+                                        ctx=None):
+        """methods/method_StereoMatching.h:185-187."""
+        return stereomatch_1._guidedf_n(3, leftImg, rightImg, dispType, eps, winSize, minDisparity, numDisparity, ctx)
 
     @staticmethod
     def getCostSAD_d(leftImg, rightImg, disparity, dispType=DISPARITY_LEFT, winSize=35, ctx=None):

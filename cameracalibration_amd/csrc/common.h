@@ -197,6 +197,13 @@ int md_cost_sad_d(hipStream_t s, const u8* ref, size_t rp, const u8* oth, size_t
 int md_guided_filter_mc(hipStream_t s, const u8* guide, size_t gp, int cn, const float* dP, int H, int W, int r, double eps, int variant,
                         float* dOut, void* scratch);
 
+size_t md_similarity_bytes(int H, int W, int minD, int numD);
+int md_compute_similarity(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, double regularity, double thresC, double thresG,
+                          int minD, int numD, int border, float* dCost, void* ws);
+size_t md_asw_guidedf23_bytes(int H, int W, int which, int isLeft, int minD, int numD);
+int md_asw_guidedf23(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int which, int isLeft, double eps, int win,
+                     int minD, int numD, float* dDisp, void* ws);
+
 // cost kinds of md_cost_box_wta
 enum { MD_COST_HAMMING = 0, MD_COST_HAMMING_SQR = 1, MD_COST_ABSDIFF_SQR = 2, MD_COST_ABSDIFF = 3 };
 // output kinds

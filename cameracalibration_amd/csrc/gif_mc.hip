@@ -424,6 +424,135 @@ int md_guided_filter_mc(hipStream_t s, const u8* guide, size_t gp, int cn, const
     return md_mc_filter_wta(s, g, H, W, r, eps, variant, 1, 0, dP, nullptr, 0, dOut, nullptr, scratch);
 }
 
+// ---- computeSimilarity (colour + gradient cost) and the two matchers that filter other cost volumes ---------------------
+
+namespace {
+// filter2D(img, CV_32F, [-3 0 3; -10 0 10; -3 0 3]) of an interleaved 3-channel image, BORDER_REFLECT_101 (integer sums: exact)
+__global__ __launch_bounds__(256) void mc_sobel3_kernel(const u8* __restrict__ img, size_t pitch, int H, int W, float* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int xl = mc_r101(x - 1, W), xr = mc_r101(x + 1, W);
+    const u8* r0 = img + (size_t)mc_r101(y - 1, H) * pitch;
+    const u8* r1 = img + (size_t)y * pitch;
+    const u8* r2 = img + (size_t)mc_r101(y + 1, H) * pitch;
+    for (int c = 0; c < 3; c++) {
+        const int s = 3 * ((int)r0[xr * 3 + c] - (int)r0[xl * 3 + c]) + 10 * ((int)r1[xr * 3 + c] - (int)r1[xl * 3 + c]) +
+                      3 * ((int)r2[xr * 3 + c] - (int)r2[xl * 3 + c]);
+        out[((size_t)y * W + x) * 3 + c] = (float)s;
+    }
+}
+
+// one slice value per thread (method_StereoMatching.cpp:1145-1179, evaluated as the library evaluates those expressions)
+struct McSimArgs {
+    const u8* L; size_t lp; const u8* Rb; size_t rp;       // left view, right view padded on the left by maxOff (REFLECT)
+    const float* sL; const float* sR;                      // their gradients: [H][W][3], [H][Wp][3]
+    int H, W, Wp, maxOff, minD;
+    float third, betaC, tG, wC, wG; double thresC;
+    float* out; size_t sliceStride; int outPitch, border;  // slice k: out + k * sliceStride, rows of outPitch floats, `border` cells on every side
+};
+__global__ __launch_bounds__(256) void mc_similarity_kernel(McSimArgs a)
+{
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, k = blockIdx.z;
+    const int OW = a.W + 2 * a.border;
+    if (ox >= OW) return;
+    // the padded overload borders every slice with BORDER_REFLECT (:1342-1347): the value of the reflected pixel
+    const int x = mc_reflect(ox - a.border, a.W), y = mc_reflect(oy - a.border, a.H);
+    const int off = a.maxOff - (a.minD + k);
+    int c[3]; float g[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const int p = a.L[(size_t)y * a.lp + x * 3 + ch], q = a.Rb[(size_t)y * a.rp + (size_t)(off + x) * 3 + ch];
+        c[ch] = p > q ? p - q : q - p;
+        g[ch] = fabsf(__fsub_rn(a.sL[((size_t)y * a.W + x) * 3 + ch], a.sR[((size_t)y * a.Wp + off + x) * 3 + ch]));
+    }
+    const int m1 = min(c[0] + c[1], 255);
+    const int colour = min(__float2int_rn(__fadd_rn(__fmul_rn((float)m1, a.third), __fmul_rn((float)c[2], a.third))), 255);
+    float cc = 0.f;
+    if ((double)colour > a.thresC) cc = (float)min(max(__float2int_rn(__fadd_rn(__fmul_rn(255.0f, a.betaC), (float)colour)), 0), 255);
+    const float grad = __fadd_rn(__fmul_rn(__fadd_rn(g[0], g[1]), a.third), __fmul_rn(g[2], a.third));
+    const float cg = grad > a.tG ? __fadd_rn(__fmul_rn(254.0f, a.tG), grad) : __fmul_rn(255.0f, a.tG);
+    a.out[(size_t)k * a.sliceStride + (size_t)oy * a.outPitch + ox] = __fadd_rn(__fmul_rn(cc, a.wC), __fmul_rn(cg, a.wG));
+}
+}  // namespace
+
+size_t md_similarity_bytes(int H, int W, int minD, int numD)
+{
+    const int Wp = W + minD + numD - 1;
+    return md_align((size_t)H * md_align((size_t)Wp * 3, 256), 256) + md_align((size_t)H * W * 12, 256) + md_align((size_t)H * Wp * 12, 256);
+}
+// dL / dR: interleaved 3-channel views (pitch bytes).  dCost: numD slices of (H + 2 border) x (W + 2 border) floats.
+int md_compute_similarity(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, double regularity, double thresC, double thresG,
+                          int minD, int numD, int border, float* dCost, void* ws)
+{
+    MD_REQUIRE(numD > 0 && minD >= 0 && border >= 0, MDISP_E_BADARG, "bad disparity range");
+    const int maxOff = minD + numD - 1, Wp = W + maxOff;
+    const size_t pP = md_align((size_t)Wp * 3, 256);
+    u8* base = (u8*)ws;
+    auto take = [&](size_t bytes) { u8* p = base; base += md_align(bytes, 256); return p; };
+    u8* Rb = take((size_t)H * pP);
+    float* sL = (float*)take((size_t)H * W * 12);
+    float* sR = (float*)take((size_t)H * Wp * 12);
+    mc_pad_reflect_kernel<<<dim3((Wp + 255) / 256, H), 256, 0, s>>>(dR, pitch, W, 3, maxOff, Wp, Rb, pP);
+    mc_sobel3_kernel<<<dim3((W + 255) / 256, H), 256, 0, s>>>(dL, pitch, H, W, sL);
+    mc_sobel3_kernel<<<dim3((Wp + 255) / 256, H), 256, 0, s>>>(Rb, pP, H, Wp, sR);
+    McSimArgs a{};
+    a.L = dL; a.lp = pitch; a.Rb = Rb; a.rp = pP; a.sL = sL; a.sR = sR; a.H = H; a.W = W; a.Wp = Wp; a.maxOff = maxOff; a.minD = minD;
+    a.third = (float)(1.0 / 3.0); a.betaC = (float)(thresC / 255.0); a.tG = (float)thresG;
+    a.wC = (float)(1.0 - regularity); a.wG = (float)regularity; a.thresC = thresC;
+    a.out = dCost; a.border = border; a.outPitch = W + 2 * border; a.sliceStride = (size_t)(H + 2 * border) * (W + 2 * border);
+    mc_similarity_kernel<<<dim3((W + 2 * border + 255) / 256, H + 2 * border, numD), 256, 0, s>>>(a);
+    MD_HIP(hipGetLastError());
+    return MDISP_OK;
+}
+
+// computeAdaptiveWeight_GuidedF_2 (which = 2) / _3 (which = 3) on interleaved 3-channel device views
+size_t md_asw_guidedf23_bytes(int H, int W, int which, int isLeft, int minD, int numD)
+{
+    const int Wp = W + minD + numD - 1;
+    const size_t N = (size_t)H * W;
+    size_t b = md_align(N * 4 * numD, 256);
+    if (which == 2) b += md_similarity_bytes(H, W, minD, numD) + md_mc_scratch_bytes(H, W, 3, numD, W, 0);
+    else b += md_align((size_t)H * md_align(W, 256), 256) * 2 + md_ncc_bytes(H, W, minD, numD) + md_align((size_t)H * md_align((size_t)Wp * 3, 256), 256) +
+              md_mc_scratch_bytes(H, W, isLeft ? 6 : 3, numD, isLeft ? W : W, isLeft ? Wp : 0);
+    return b + 4096;
+}
+int md_asw_guidedf23(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, int H, int W, int which, int isLeft, double eps, int win,
+                     int minD, int numD, float* dDisp, void* ws)
+{
+    MD_REQUIRE(which == 2 || which == 3, MDISP_E_BADARG, "unknown matcher");
+    MD_REQUIRE(numD > 0 && minD >= 0, MDISP_E_BADARG, "bad disparity range");
+    MD_REQUIRE(win > 0 && win % 2 == 1, MDISP_E_BADARG, "winsize must be odd");
+    // computeSimilarity runs for colour input and DISPARITY_LEFT only: its other branches multiply a CV_32F matrix by a
+    // CV_8U mask, which the library refuses (method_StereoMatching.cpp:1218, 1257, 1292)
+    MD_REQUIRE(which != 2 || isLeft, MDISP_E_UNSUPPORTED, "computeAdaptiveWeight_GuidedF_2: computeSimilarity fails for DISPARITY_RIGHT in the reference");
+    const size_t N = (size_t)H * W;
+    const int maxOff = minD + numD - 1, Wp = W + maxOff;
+    u8* base = (u8*)ws;
+    auto take = [&](size_t bytes) { u8* p = base; base += md_align(bytes, 256); return p; };
+    float* vol = (float*)take(N * 4 * numD);
+    McGuideHost g{};
+    if (which == 2) {
+        void* sim = take(md_similarity_bytes(H, W, minD, numD));
+        MD_TRY(md_compute_similarity(s, dL, dR, pitch, H, W, 0.4, 10.0, 50.0, minD, numD, 0, vol, sim));        // :3808
+        g.a = dL; g.ap = pitch; g.acn = 3; g.aW = W;                                                             // :3822
+    } else {
+        const size_t pG = md_align(W, 256), pP = md_align((size_t)Wp * 3, 256);
+        u8* gl = take((size_t)H * pG); u8* gr = take((size_t)H * pG);
+        void* nccWs = take(md_ncc_bytes(H, W, minD, numD));
+        u8* othP = take((size_t)H * pP);
+        MD_TRY(md_bgr2gray(s, dL, pitch, H, W, gl, pG, 1));          // computeNCC converts with COLOR_RGB2GRAY (:934-942)
+        MD_TRY(md_bgr2gray(s, dR, pitch, H, W, gr, pG, 1));
+        MD_TRY(md_ncc(s, gl, gr, pG, H, W, isLeft, win, minD, numD, nccWs, nullptr, vol));                       // :3895
+        if (isLeft) {      // the six-channel guide of computeAdaptiveWeight_GuidedF (:3902-3909)
+            mc_pad_reflect_kernel<<<dim3((Wp + 255) / 256, H), 256, 0, s>>>(dR, pitch, W, 3, maxOff, Wp, othP, pP);
+            g.a = dL; g.ap = pitch; g.acn = 3; g.aW = W;
+            g.b = othP; g.bp = pP; g.bcn = 3; g.bW = Wp; g.bOff0 = maxOff - minD; g.bOffStep = -1;
+        } else { g.a = dR; g.ap = pitch; g.acn = 3; g.aW = W; }      // getGuidedFilter(rightImg, ...) (:3924)
+    }
+    return md_mc_filter_wta(s, g, H, W, win, eps, 1, numD, minD, vol, nullptr, 0, nullptr, dDisp, base);
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------------------------
 
 namespace {
@@ -546,6 +675,65 @@ extern "C" int mdisp_guided_filter_multi(mdisp_ctx* c, const mdisp_image* guide,
         MD_TRY(md_h2d_2d(c, base + o_p, (size_t)W * 4, P->data, P->step_bytes, (size_t)W * 4, H));
     }
     MD_TRY(md_guided_filter_mc(c->stream, base + o_g, pg, cn, (const float*)(base + o_p), H, W, r, eps, variant, (float*)(base + o_d), base + o_ws));
+    MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 4, (size_t)W * 4, H));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_compute_similarity(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, int is_left, double regularity, double thresC,
+                                        double thresG, int winSize, int minD, int numD, float* cost)
+{
+    MD_REQUIRE(c && cost, MDISP_E_BADARG, "null argument");
+    MD_TRY(mc_check_u8(L, "left"));
+    MD_TRY(mc_check_u8(R, "right"));
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols, MDISP_E_BADARG, "left/right size mismatch");
+    MD_REQUIRE(winSize == 0 || winSize % 2 == 1, MDISP_E_BADARG, "winsize must be odd");
+    MD_REQUIRE(numD > 0 && minD >= 0, MDISP_E_BADARG, "bad disparity range");
+    // every other branch of the reference multiplies a CV_32F matrix by a CV_8U mask and fails in the library
+    MD_REQUIRE(L->channels == 3 && R->channels == 3 && is_left, MDISP_E_UNSUPPORTED,
+               "computeSimilarity runs in the reference for 3-channel views and DISPARITY_LEFT only");
+    const int H = L->rows, W = L->cols, border = winSize / 2;
+    MD_HIP(hipSetDevice(c->device));
+    const size_t p3 = md_align((size_t)W * 3, 256), outN = (size_t)(H + 2 * border) * (W + 2 * border) * numD;
+    McCarver cv;
+    const size_t o_l = cv.take(p3 * H), o_r = cv.take(p3 * H), o_c = cv.take(outN * 4), o_ws = cv.take(md_similarity_bytes(H, W, minD, numD));
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base + o_l, p3, L->data, L->step_bytes, (size_t)W * 3, H));
+    MD_TRY(md_h2d_2d(c, base + o_r, p3, R->data, R->step_bytes, (size_t)W * 3, H));
+    MD_TRY(md_compute_similarity(c->stream, base + o_l, base + o_r, p3, H, W, regularity, thresC, thresG, minD, numD, border, (float*)(base + o_c),
+                                 base + o_ws));
+    MD_HIP(hipMemcpyAsync(cost, base + o_c, outN * 4, hipMemcpyDeviceToHost, c->stream));
+    MD_HIP(hipStreamSynchronize(c->stream));
+    return MDISP_OK;
+}
+
+extern "C" int mdisp_adaptive_weight_guidedf_n(mdisp_ctx* c, const mdisp_image* L, const mdisp_image* R, int which, int is_left, double eps,
+                                               int winSize, int minD, int numD, mdisp_image* out)
+{
+    if (which == 1) return mdisp_adaptive_weight_guidedf(c, L, R, is_left, eps, winSize, minD, numD, out);
+    MD_REQUIRE(c, MDISP_E_BADARG, "null context");
+    MD_REQUIRE(which == 2 || which == 3, MDISP_E_BADARG, "which: 1, 2 or 3");
+    MD_TRY(mc_check_u8(L, "left"));
+    MD_TRY(mc_check_u8(R, "right"));
+    MD_REQUIRE(L->rows == R->rows && L->cols == R->cols && L->channels == R->channels, MDISP_E_BADARG, "left/right size mismatch");
+    MD_REQUIRE(L->channels == 3, MDISP_E_UNSUPPORTED, "the guided-filter matchers need 3-channel views (their guides fail on others in the reference)");
+    MD_REQUIRE(numD > 0 && minD >= 0, MDISP_E_BADARG, "bad disparity range");
+    MD_REQUIRE(winSize > 0 && winSize % 2 == 1, MDISP_E_BADARG, "winsize must be odd");
+    MD_REQUIRE(which != 2 || is_left, MDISP_E_UNSUPPORTED, "computeAdaptiveWeight_GuidedF_2: computeSimilarity fails for DISPARITY_RIGHT in the reference");
+    MD_TRY(md_mc_check_window(winSize));
+    const int H = L->rows, W = L->cols;
+    MD_TRY(mc_check_f32_out(out, H, W, "out"));
+    MD_HIP(hipSetDevice(c->device));
+    const size_t p3 = md_align((size_t)W * 3, 256);
+    McCarver cv;
+    const size_t o_l = cv.take(p3 * H), o_r = cv.take(p3 * H), o_d = cv.take((size_t)H * W * 4),
+                 o_ws = cv.take(md_asw_guidedf23_bytes(H, W, which, is_left != 0, minD, numD));
+    u8* base = (u8*)mdisp_ws(c, cv.off);
+    if (!base) return MDISP_E_NOMEM;
+    MD_TRY(md_h2d_2d(c, base + o_l, p3, L->data, L->step_bytes, (size_t)W * 3, H));
+    MD_TRY(md_h2d_2d(c, base + o_r, p3, R->data, R->step_bytes, (size_t)W * 3, H));
+    MD_TRY(md_asw_guidedf23(c->stream, base + o_l, base + o_r, p3, H, W, which, is_left != 0, eps, winSize, minD, numD, (float*)(base + o_d), base + o_ws));
     MD_TRY(md_d2h_2d(c, out->data, out->step_bytes, base + o_d, (size_t)W * 4, (size_t)W * 4, H));
     MD_HIP(hipStreamSynchronize(c->stream));
     return MDISP_OK;

@@ -488,6 +488,29 @@ int mdisp_guided_filter_multi(mdisp_ctx*, const mdisp_image* guide, const mdisp_
 int mdisp_adaptive_weight_guidedf(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, int is_left, double eps, int winSize,
                                   int minDisparity, int numDisparity, mdisp_image* out);
 
+/* stereomatch_1::computeSimilarity (methods/method_StereoMatching.cpp:1108-1348; .h both overloads): colour + gradient cost
+ * slices.  The reference function runs for CV_8UC3 views and DISPARITY_LEFT only -- its other branches multiply a CV_32F
+ * matrix by a CV_8U mask (:1218, :1257, :1292), which cv::multiply refuses -- so every other input gives
+ * MDISP_E_UNSUPPORTED.  Slice k (candidate minDisparity + k), as the library evaluates the expressions:
+ *   colour   = round(saturate(c0 + c1) / 3 + c2 / 3) of the per-channel |L - R|; cost = saturate(colour + thresC) where colour >
+ *              thresC, else 0 (the reference's mask arithmetic, :1152-1158)
+ *   gradient = |filter2D([-3 0 3; -10 0 10; -3 0 3])| differences, (g0 + g1) / 3 + g2 / 3; cost = g + 254 * thresG where g >
+ *              thresG, else 255 * thresG (:1166-1175: bitwise_not of a 0 / 1 mask)
+ *   slice    = (1 - regularity) * colour cost + regularity * gradient cost, float.
+ * winSize = 0: the nine-argument overload, numDisparity slices of rows x cols floats.  Odd winSize: the ten-argument
+ * overload (:1331-1348), every slice bordered by winSize / 2 cells of BORDER_REFLECT on all sides.  Even winSize:
+ * MDISP_E_BADARG (the reference returns without slices).  cost: host floats. */
+int mdisp_compute_similarity(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, int is_left, double regularity, double thresC,
+                             double thresG, int winSize, int minDisparity, int numDisparity, float* cost);
+
+/* stereomatch_1::computeAdaptiveWeight_GuidedF (which = 1), _GuidedF_2 (2: computeSimilarity(0.4, 10, 50) slices filtered with
+ * the reference view as 3-channel guide, .cpp:3794-3868; DISPARITY_RIGHT: MDISP_E_UNSUPPORTED, as computeSimilarity) and
+ * _GuidedF_3 (3: computeNCC cost-volume slices; DISPARITY_LEFT filters with the six-channel guide, DISPARITY_RIGHT with the
+ * right view, .cpp:3881-3955).  stereoMatching calls them with (0.01, 15, 10, 150), (0.01, 13, 10, 150) and
+ * (1e-6, 15, 0, 64), methods/methods.cpp:1801-1809. */
+int mdisp_adaptive_weight_guidedf_n(mdisp_ctx*, const mdisp_image* L, const mdisp_image* R, int which, int is_left, double eps,
+                                    int winSize, int minDisparity, int numDisparity, mdisp_image* out);
+
 /* time of the most recent call's dominant kernel on this context, measured with HIP events on
  * the context's stream (milliseconds); which = 0: whole call, 1: SGM path aggregation (every scan
  * and sweep kernel of the call), 2: the separate winner-take-all kernel of the per-direction

@@ -171,6 +171,19 @@ inline cv::Mat getGuidedFilter(cv::Mat guidedImg, cv::Mat inputP, int r, double 
 inline cv::Mat computeAdaptiveWeight_GuidedF(cv::Mat leftImg, cv::Mat rightImg, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, double eps = 0.01,
                                              int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 { return mdisp::stereomatch_1::computeAdaptiveWeight_GuidedF(leftImg, rightImg, (mdisp::stereomatch_1::DisparityType)(int)dispType, eps, winSize, minDisparity, numDisparity); }
+// methods/method_StereoMatching.h:123-128, 182-187
+inline void computeSimilarity(cv::Mat leftImg, cv::Mat rightImg, std::vector<cv::Mat>& cost_d_imgs, double regularity, double thresC, double thresG,
+                              DisparityType dispType, int minDisparity, int numDisparity)
+{ mdisp::stereomatch_1::computeSimilarity(leftImg, rightImg, cost_d_imgs, regularity, thresC, thresG, (mdisp::stereomatch_1::DisparityType)(int)dispType, minDisparity, numDisparity); }
+inline void computeSimilarity(cv::Mat leftImg, cv::Mat rightImg, std::vector<cv::Mat>& cost_d_imgs, double regularity, double thresC, double thresG,
+                              DisparityType dispType, int winSize, int minDisparity, int numDisparity)
+{ mdisp::stereomatch_1::computeSimilarity(leftImg, rightImg, cost_d_imgs, regularity, thresC, thresG, (mdisp::stereomatch_1::DisparityType)(int)dispType, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeAdaptiveWeight_GuidedF_2(cv::Mat leftImg, cv::Mat rightImg, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, double eps = 0.01,
+                                               int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return mdisp::stereomatch_1::computeAdaptiveWeight_GuidedF_2(leftImg, rightImg, (mdisp::stereomatch_1::DisparityType)(int)dispType, eps, winSize, minDisparity, numDisparity); }
+inline cv::Mat computeAdaptiveWeight_GuidedF_3(cv::Mat leftImg, cv::Mat rightImg, DisparityType dispType = MDISP_CV_DISPARITY_LEFT, double eps = 1e-6,
+                                               int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return mdisp::stereomatch_1::computeAdaptiveWeight_GuidedF_3(leftImg, rightImg, (mdisp::stereomatch_1::DisparityType)(int)dispType, eps, winSize, minDisparity, numDisparity); }
 }  // namespace stereomatch_1
 
 #endif  // MDISP_CV_HPP

@@ -427,14 +427,16 @@ enum StereoMatchingAlgorithms {
 
 namespace detail {
 // stereomatch_1::computeAdaptiveWeight_GuidedF, methods/method_StereoMatching.cpp:3685-3781 (CV_8UC3 views -> CV_32F map)
-template <class M> M adaptive_weight_guidedf(M leftImg, M rightImg, bool isLeft, double eps, int winSize, int minDisparity, int numDisparity)
+// which: 1 = computeAdaptiveWeight_GuidedF, 2 = _GuidedF_2, 3 = _GuidedF_3 (:3794-3955)
+template <class M> M adaptive_weight_guidedf(M leftImg, M rightImg, bool isLeft, double eps, int winSize, int minDisparity, int numDisparity,
+                                             int which = 1)
 {
     typedef mat_traits<M> T;
     mdisp_image l = T::view(leftImg), r = T::view(rightImg);
     M out;
     T::create(out, l.rows, l.cols, MDISP_32F, 1);
     mdisp_image o = T::view(out);
-    check(mdisp_adaptive_weight_guidedf(Context::forThisThread().handle(), &l, &r, isLeft, eps, winSize, minDisparity, numDisparity, &o));
+    check(mdisp_adaptive_weight_guidedf_n(Context::forThisThread().handle(), &l, &r, which, isLeft, eps, winSize, minDisparity, numDisparity, &o));
     return out;
 }
 }  // namespace detail
@@ -449,7 +451,13 @@ template <class M> void stereoMatching(M srcLeft, M srcRight, M& disparityMap, S
     case ADAPTIVE_WEIGHT_GUIDED_FILTER:      // methods.cpp:1801-1803
         disparityMap = detail::adaptive_weight_guidedf(srcLeft, srcRight, true, 0.01, 15, 10, 150);
         break;
-    default: std::cout << "stereoMatching: algorithm " << (int)algorithmType << " is not built (BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER are)" << std::endl;
+    case ADAPTIVE_WEIGHT_GUIDED_FILTER_2:    // methods.cpp:1804-1806
+        disparityMap = detail::adaptive_weight_guidedf(srcLeft, srcRight, true, 0.01, 13, 10, 150, 2);
+        break;
+    case ADAPTIVE_WEIGHT_GUIDED_FILTER_3:    // methods.cpp:1807-1809
+        disparityMap = detail::adaptive_weight_guidedf(srcLeft, srcRight, true, 1e-6, 15, 0, 64, 3);
+        break;
+    default: std::cout << "stereoMatching: algorithm " << (int)algorithmType << " is not built (BM, SGBM and ADAPTIVE_WEIGHT_GUIDED_FILTER* are)" << std::endl;
     }
 }
 
@@ -624,6 +632,43 @@ template <class M> M getGuidedFilter(M guidedImg, M inputP, int r, double eps)
 template <class M> M computeAdaptiveWeight_GuidedF(M leftImg, M rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 0.01,
                                                    int winSize = 35, int minDisparity = 186, int numDisparity = 144)
 { return detail::adaptive_weight_guidedf(leftImg, rightImg, dispType == DISPARITY_LEFT, eps, winSize, minDisparity, numDisparity); }
+// methods/method_StereoMatching.h:182-187
+template <class M> M computeAdaptiveWeight_GuidedF_2(M leftImg, M rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 0.01,
+                                                     int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return detail::adaptive_weight_guidedf(leftImg, rightImg, dispType == DISPARITY_LEFT, eps, winSize, minDisparity, numDisparity, 2); }
+template <class M> M computeAdaptiveWeight_GuidedF_3(M leftImg, M rightImg, DisparityType dispType = DISPARITY_LEFT, double eps = 1e-6,
+                                                     int winSize = 35, int minDisparity = 186, int numDisparity = 144)
+{ return detail::adaptive_weight_guidedf(leftImg, rightImg, dispType == DISPARITY_LEFT, eps, winSize, minDisparity, numDisparity, 3); }
+// computeSimilarity (method_StereoMatching.cpp:1108-1348): border = 0 for the nine-argument overload, winSize / 2 for the other
+template <class M> void computeSimilarity_(M leftImg, M rightImg, std::vector<M>& cost_d_imgs, double regularity, double thresC, double thresG,
+                                           DisparityType dispType, int winSize, int minDisparity, int numDisparity)
+{
+    typedef mat_traits<M> T;
+    cost_d_imgs.clear();
+    mdisp_image l = T::view(leftImg), r = T::view(rightImg);
+    if (l.rows != r.rows || l.cols != r.cols) return;
+    const int b = winSize / 2, OH = l.rows + 2 * b, OW = l.cols + 2 * b;
+    std::vector<float> vol((size_t)numDisparity * OH * OW);
+    detail::check(mdisp_compute_similarity(Context::forThisThread().handle(), &l, &r, dispType == DISPARITY_LEFT, regularity, thresC, thresG, winSize,
+                                           minDisparity, numDisparity, vol.data()));
+    for (int k = 0; k < numDisparity; k++) {
+        M slice;
+        T::create(slice, OH, OW, MDISP_32F, 1);
+        mdisp_image sv = T::view(slice);
+        for (int y = 0; y < OH; y++)
+            std::memcpy((char*)sv.data + (size_t)y * sv.step_bytes, vol.data() + ((size_t)k * OH + y) * OW, (size_t)OW * sizeof(float));
+        cost_d_imgs.push_back(slice);
+    }
+}
+template <class M> void computeSimilarity(M leftImg, M rightImg, std::vector<M>& cost_d_imgs, double regularity, double thresC, double thresG,
+                                          DisparityType dispType, int minDisparity, int numDisparity)
+{ computeSimilarity_(leftImg, rightImg, cost_d_imgs, regularity, thresC, thresG, dispType, 0, minDisparity, numDisparity); }
+template <class M> void computeSimilarity(M leftImg, M rightImg, std::vector<M>& cost_d_imgs, double regularity, double thresC, double thresG,
+                                          DisparityType dispType, int winSize, int minDisparity, int numDisparity)
+{
+    if (winSize % 2 == 0) return;
+    computeSimilarity_(leftImg, rightImg, cost_d_imgs, regularity, thresC, thresG, dispType, winSize, minDisparity, numDisparity);
+}
 }  // namespace stereomatch_1
 
 }  // namespace mdisp

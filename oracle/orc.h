@@ -82,6 +82,13 @@ void orc_guided_filter_mc(const float* G /* cn planes, normalised */, int cn, co
 int orc_adaptive_weight_guidedf(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int isLeft, double eps, int winSize, int minD,
                                 int numD, float* depth);
 
+/* stereomatch_1::computeSimilarity (colour, DISPARITY_LEFT) and computeAdaptiveWeight_GuidedF_2 / _3
+ * (methods/method_StereoMatching.cpp:1108-1180, 3794-3955) */
+int orc_compute_similarity(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int isLeft, double regularity, double thresC,
+                           double thresG, int minD, int numD, float* cost);
+int orc_adaptive_weight_guidedf_23(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int which, int isLeft, double eps, int winSize,
+                                   int minD, int numD, float* depth);
+
 /* cv::StereoSGBM parameters (create() argument order) */
 enum { ORC_SGBM_MODE_SGBM = 0, ORC_SGBM_MODE_HH = 1 };
 typedef struct {

@@ -426,6 +426,31 @@ def adaptive_weight_guidedf(L, R, is_left=True, eps=0.01, winSize=15, minDispari
     return None if rc else out
 
 
+def compute_similarity(L, R, is_left=True, regularity=0.4, thresC=10.0, thresG=50.0, minDisparity=0, numDisparity=30):
+    """stereomatch_1::computeSimilarity (nine-argument overload) on H x W x 3 uint8 images -> float32 [numDisparity, H, W],
+    or None where the reference fails or returns nothing."""
+    L = np.ascontiguousarray(L, np.uint8)
+    R = np.ascontiguousarray(R, np.uint8)
+    cn = 1 if L.ndim == 2 else L.shape[2]
+    H, W = L.shape[:2]
+    out = np.empty((numDisparity, H, W), np.float32)
+    rc = lib().orc_compute_similarity(_p(L), _p(R), H, W, cn, int(is_left), C.c_double(regularity), C.c_double(thresC), C.c_double(thresG),
+                                      minDisparity, numDisparity, _p(out))
+    return None if rc else out
+
+
+def adaptive_weight_guidedf_23(L, R, which, is_left=True, eps=0.01, winSize=15, minDisparity=10, numDisparity=150):
+    """stereomatch_1::computeAdaptiveWeight_GuidedF_2 (which = 2) / _3 (which = 3) -> float32 map, or None where the reference fails."""
+    L = np.ascontiguousarray(L, np.uint8)
+    R = np.ascontiguousarray(R, np.uint8)
+    cn = 1 if L.ndim == 2 else L.shape[2]
+    H, W = L.shape[:2]
+    out = np.empty((H, W), np.float32)
+    rc = lib().orc_adaptive_weight_guidedf_23(_p(L), _p(R), H, W, cn, which, int(is_left), C.c_double(eps), winSize, minDisparity,
+                                              numDisparity, _p(out))
+    return None if rc else out
+
+
 def ncc_disparity(L, R, is_left=True, winSize=7, minDisparity=0, numDisparity=30):
     """stereomatch_1::computeNCC, map overload (methods/method_StereoMatching.cpp:915-1015) -> float32, or None where the
     reference refuses (even window)."""

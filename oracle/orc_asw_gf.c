@@ -190,3 +190,145 @@ int orc_adaptive_weight_guidedf(const uint8_t* L, const uint8_t* R, int H, int W
     free(othP); free(refG); free(othG); free(cost); free(Pn); free(G); free(out); free(best);
     return rc;
 }
+
+/*
+ * stereomatch_1::computeSimilarity, nine-argument overload, colour input with DISPARITY_LEFT
+ * (method_StereoMatching.cpp:1108-1180) -- the only branch of that function that runs: the others multiply a CV_32F
+ * matrix by a CV_8U mask (:1218, :1257, :1292), which the library refuses.  As the expressions evaluate in OpenCV 4.1:
+ *   colour: |L - R(x - d)| per channel (8-bit); (c0 + c1 + c2) / 3 = addWeighted(saturate(c0 + c1), 1/3, c2, 1/3) in float,
+ *           rounded to 8 bits (:1152); where that exceeds thresC the cost is saturate(colour + thresC), elsewhere 0
+ *           (:1155-1157: colour.mul(mask / 255) + thresC * (mask / 255)), then float.
+ *   gradient: filter2D with [-3 0 3; -10 0 10; -3 0 3] (BORDER_REFLECT_101; the right view is filtered after its
+ *           BORDER_REFLECT padding) as float, |difference| per channel, (g0 + g1) then addWeighted(., 1/3, g2, 1/3) in
+ *           float (:1166); where that exceeds thresG the cost is g + 254 * thresG, elsewhere 255 * thresG (:1170-1175:
+ *           the bitwise_not of a 0 / 1 mask is 255 / 254).
+ *   slice = addWeighted(colour cost, 1 - regularity, gradient cost, regularity) in float (:1177).
+ * L, R: interleaved 3-channel 8-bit images; cost: numD slices of H * W floats.  Returns -2 for the inputs on which the
+ * reference fails (gray images, DISPARITY_RIGHT) and -1 for a size mismatch (it returns without slices).
+ */
+static void sobel3(const uint8_t* img, int H, int W, float* out /* H*W*3 */)
+{
+    static const int kx[3] = {-3, -10, -3};
+#pragma omp parallel for
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < 3; c++) {
+                int s = 0;
+                for (int i = -1; i <= 1; i++) {
+                    const int yy = orc_reflect101(y + i, H), xl = orc_reflect101(x - 1, W), xr = orc_reflect101(x + 1, W);
+                    s += kx[i + 1] * ((int)img[((long)yy * W + xl) * 3 + c] - (int)img[((long)yy * W + xr) * 3 + c]);
+                }
+                out[((long)y * W + x) * 3 + c] = (float)s;
+            }
+}
+
+int orc_compute_similarity(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int isLeft, double regularity, double thresC,
+                           double thresG, int minD, int numD, float* cost)
+{
+    if (!L || !R || !cost || numD <= 0 || minD < 0) return -1;
+    if (cn != 3 || !isLeft) return -2;
+    const long N = (long)H * W;
+    const int maxOff = minD + numD - 1, Wp = W + maxOff;
+    uint8_t* Rb = (uint8_t*)malloc((size_t)H * Wp * 3);
+    pad_reflect_cn(R, H, W, 3, maxOff, 0, Rb);
+    float* sL = fnew(N * 3); float* sR = fnew((long)H * Wp * 3);
+    sobel3(L, H, W, sL);
+    sobel3(Rb, H, Wp, sR);
+    const float third = (float)(1.0 / 3.0), betaC = (float)(thresC / 255.0), tG = (float)thresG;
+    const float wC = (float)(1.0 - regularity), wG = (float)regularity;
+    for (int k = 0; k < numD; k++) {
+        const int off = maxOff - (minD + k);
+        float* out = cost + (long)k * N;
+#pragma omp parallel for
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                int c[3]; float g[3];
+                for (int ch = 0; ch < 3; ch++) {
+                    const int a = L[((long)y * W + x) * 3 + ch], b = Rb[((long)y * Wp + off + x) * 3 + ch];
+                    c[ch] = a > b ? a - b : b - a;
+                    g[ch] = fabsf(sL[((long)y * W + x) * 3 + ch] - sR[((long)y * Wp + off + x) * 3 + ch]);
+                }
+                int m1 = c[0] + c[1]; if (m1 > 255) m1 = 255;
+                volatile float t0 = (float)m1 * third, t1 = (float)c[2] * third;
+                volatile float cs = t0 + t1;
+                int colour = (int)lrintf(cs); if (colour > 255) colour = 255;
+                float cc = 0.f;
+                if ((double)colour > thresC) {
+                    volatile float u0 = 255.0f * betaC;
+                    volatile float u1 = u0 + (float)colour;
+                    int v = (int)lrintf(u1); if (v > 255) v = 255; if (v < 0) v = 0;
+                    cc = (float)v;
+                }
+                volatile float g01 = g[0] + g[1];
+                volatile float h0 = g01 * third, h1 = g[2] * third;
+                volatile float grad = h0 + h1;
+                float cg;
+                if (grad > tG) { volatile float p = 254.0f * tG; cg = p + grad; }
+                else { volatile float p = 255.0f * tG; cg = p; }
+                volatile float e0 = cc * wC, e1 = cg * wG;
+                out[(long)y * W + x] = e0 + e1;
+            }
+    }
+    free(Rb); free(sL); free(sR);
+    return 0;
+}
+
+/* COLOR_RGB2GRAY on a BGR image, as computeNCC converts its colour input (method_StereoMatching.cpp:934-942): the first
+ * channel gets the red weight */
+static void rgb_order_gray(const uint8_t* img, long n, uint8_t* gray)
+{
+    for (long i = 0; i < n; i++)
+        gray[i] = (uint8_t)((img[3 * i] * 4899 + img[3 * i + 1] * 9617 + img[3 * i + 2] * 1868 + 8192) >> 14);
+}
+
+/*
+ * computeAdaptiveWeight_GuidedF_2 (:3794-3868): slices from computeSimilarity(L, R, 0.4, 10, 50, dispType, minD, numD),
+ * each filtered with getGuidedFilter(left view (3 channels), slice, winSize, eps), first minimum.  DISPARITY_RIGHT fails
+ * inside computeSimilarity (-2).
+ * computeAdaptiveWeight_GuidedF_3 (:3881-3955): slices from the cost-volume overload of computeNCC; DISPARITY_LEFT filters
+ * with the six-channel guide of computeAdaptiveWeight_GuidedF, DISPARITY_RIGHT with the right view alone (:3924).
+ */
+int orc_adaptive_weight_guidedf_23(const uint8_t* L, const uint8_t* R, int H, int W, int cn, int which, int isLeft, double eps, int winSize,
+                                   int minD, int numD, float* depth)
+{
+    if (!L || !R || !depth || numD <= 0 || minD < 0) return -1;
+    if (cn != 3) return -2;
+    if (winSize % 2 == 0) return -3;
+    const long N = (long)H * W;
+    const int maxOff = minD + numD - 1, Wp = W + maxOff;
+    float* vol = fnew(N * numD);
+    int rc;
+    if (which == 2) rc = orc_compute_similarity(L, R, H, W, cn, isLeft, 0.4, 10.0, 50.0, minD, numD, vol);
+    else {
+        uint8_t* gl = (uint8_t*)malloc((size_t)N); uint8_t* gr = (uint8_t*)malloc((size_t)N);
+        rgb_order_gray(L, N, gl); rgb_order_gray(R, N, gr);
+        rc = orc_ncc_volume(gl, gr, H, W, isLeft, winSize, minD, numD, vol);
+        free(gl); free(gr);
+    }
+    if (rc) { free(vol); return rc < 0 ? rc : -3; }
+    const int six = which == 3 && isLeft;
+    uint8_t* othP = NULL;
+    if (six) { othP = (uint8_t*)malloc((size_t)H * Wp * cn); pad_reflect_cn(R, H, W, cn, maxOff, 0, othP); }
+    const int gcn = six ? 2 * cn : cn;
+    float* G = fnew(N * gcn); float* Pn = fnew(N); float* out = fnew(N);
+    double* best = (double*)malloc(sizeof(double) * (size_t)N);
+    for (long i = 0; i < N; i++) { best[i] = DBL_MAX; depth[i] = 0.f; }
+    const uint8_t* single = which == 2 ? (isLeft ? L : R) : R;      /* :3822 / :3837; :3924 */
+    if (!six) {
+        int mn = 255, mx = 0;
+        for (long i = 0; i < N * cn; i++) { if (single[i] < mn) mn = single[i]; if (single[i] > mx) mx = single[i]; }
+        const double scale = ((double)mx - mn > DBL_EPSILON) ? 1.0 / ((double)mx - mn) : 0.0;
+        const float sa = (float)scale, sb = (float)(0.0 - mn * scale);
+        for (long i = 0; i < N; i++)
+            for (int ch = 0; ch < cn; ch++) { volatile float t = (float)single[i * cn + ch] * sa; G[(long)ch * N + i] = t + sb; }
+    }
+    for (int i = 0; i < numD; i++) {
+        if (six) guide_planes(L, othP, Wp, numD - i - 1, H, W, cn, 1, G);
+        orc_normalize_minmax_f32(vol + (long)i * N, N, Pn);
+        orc_guided_filter_mc(G, gcn, Pn, H, W, winSize, eps, 1, out);
+        for (long p = 0; p < N; p++)
+            if ((double)out[p] < best[p]) { best[p] = (double)out[p]; depth[p] = (float)(minD + i); }
+    }
+    free(vol); free(othP); free(G); free(Pn); free(out); free(best);
+    return 0;
+}

@@ -33,4 +33,7 @@ void use_every_boundary_function(cv::Mat l, cv::Mat r, std::string xml)
     a = stereomatch_1::getGuidedFilter(l, b, 15, 0.01);
     a = stereomatch_1::computeAdaptiveWeight_GuidedF(l, r); a = stereomatch_1::computeAdaptiveWeight_GuidedF(l, r, DISPARITY_LEFT, 0.01, 15, 10, 150);
     stereoMatching(l, r, a, mdisp::ADAPTIVE_WEIGHT_GUIDED_FILTER);
+    stereomatch_1::computeSimilarity(l, r, slices, 0.4, 10, 50, DISPARITY_LEFT, 0, 30);
+    stereomatch_1::computeSimilarity(l, r, slices, 0.4, 10, 50, DISPARITY_LEFT, 7, 0, 30);
+    a = stereomatch_1::computeAdaptiveWeight_GuidedF_2(l, r); a = stereomatch_1::computeAdaptiveWeight_GuidedF_3(l, r, DISPARITY_RIGHT, 1e-6, 15, 0, 64);
 }

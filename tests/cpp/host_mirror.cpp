@@ -113,6 +113,13 @@ int main(int argc, char** argv)
         return fail("computeAdaptiveWeight_GuidedF / getCostSAD_d: empty output, or an unbordered view accepted");
     std::fwrite(dGf.data(), 4, (size_t)H * W, f);
     std::fwrite(cSad.data(), 4, (size_t)H * W, f);
+    // the colour + gradient cost slices (method_StereoMatching.h:123-125) and the matcher that filters them (:182-184)
+    std::vector<Mat> sim;
+    stereomatch_1::computeSimilarity(Lc, Rc, sim, 0.4, 10, 50, stereomatch_1::DISPARITY_LEFT, 0, 6);
+    Mat dGf2 = stereomatch_1::computeAdaptiveWeight_GuidedF_2(Lc, Rc, stereomatch_1::DISPARITY_LEFT, 0.01, 7, 0, 12);
+    if (sim.size() != 6 || dGf2.empty()) return fail("computeSimilarity / computeAdaptiveWeight_GuidedF_2: wrong slice count or empty output");
+    std::fwrite(sim[3].data(), 4, (size_t)H * W, f);
+    std::fwrite(dGf2.data(), 4, (size_t)H * W, f);
     std::fclose(f);
     std::printf("OK\n");
     return 0;

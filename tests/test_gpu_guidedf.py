@@ -128,3 +128,64 @@ def test_guidedf_refuses_what_the_reference_cannot_run(api):
     with pytest.raises(MdispError) as e:
         api.stereomatch_1.computeAdaptiveWeight_GuidedF(g, g, api.DISPARITY_LEFT, 0.01, 7, 0, 8)     # 2-channel guide
     assert e.value.code == E_UNSUPPORTED
+
+
+# ---- computeSimilarity and the matchers that filter other cost volumes ------------------------------------------------
+
+@pytest.mark.parametrize("shape,reg,tc,tg,minD,numD", [((40, 70), 0.4, 10, 50, 0, 12), ((33, 129), 0.25, 3, 20, 2, 9), ((20, 45), 0.4, 300, 5000, 0, 5)])
+def test_compute_similarity(api, orc, shape, reg, tc, tg, minD, numD):
+    """Per-pixel float arithmetic in the reference's order: the slices equal the restatement bit for bit."""
+    H, W = shape
+    L, R = _colour_pair(H + 2 * W, H, W, 4)
+    slices = ["stale"]
+    api.stereomatch_1.computeSimilarity(L, R, slices, reg, tc, tg, api.DISPARITY_LEFT, None, minD, numD)
+    exp = orc.compute_similarity(L, R, True, reg, tc, tg, minD, numD)
+    assert len(slices) == numD and np.array_equal(np.stack(slices), exp)
+    # the ten-argument overload borders every slice with BORDER_REFLECT
+    api.stereomatch_1.computeSimilarity(L, R, slices, reg, tc, tg, api.DISPARITY_LEFT, 7, minD, numD)
+    assert np.array_equal(np.stack(slices), np.pad(exp, ((0, 0), (3, 3), (3, 3)), mode="symmetric"))
+    keep = ["kept"]
+    api.stereomatch_1.computeSimilarity(L, R, keep, reg, tc, tg, api.DISPARITY_LEFT, 6, minD, numD)       # even window: returns before anything
+    assert keep == ["kept"]
+    api.stereomatch_1.computeSimilarity(L, R[:-1], keep, reg, tc, tg, api.DISPARITY_LEFT, None, minD, numD)   # size mismatch: cleared only
+    assert keep == []
+
+
+def test_compute_similarity_refuses_what_fails_in_the_reference(api):
+    from cameracalibration_amd._lib import MdispError, E_UNSUPPORTED
+    L, R = _colour_pair(9, 20, 40, 3)
+    for args in ((L, R, api.DISPARITY_RIGHT), (L[..., 0].copy(), R[..., 0].copy(), api.DISPARITY_LEFT)):
+        with pytest.raises(MdispError) as e:
+            api.stereomatch_1.computeSimilarity(args[0], args[1], [], 0.4, 10, 50, args[2], None, 0, 8)
+        assert e.value.code == E_UNSUPPORTED
+
+
+def _near_tie_check(got, exp, limit=0.003):
+    assert got.dtype == np.float32 and got.shape == exp.shape
+    assert float((got != exp).mean()) <= limit, "%d pixels differ" % int((got != exp).sum())
+
+
+@pytest.mark.parametrize("which,is_left,shape,eps,win,minD,numD", [
+    (2, True, (40, 90), 0.01, 7, 0, 12), (2, True, (60, 140), 0.01, 13, 4, 20),
+    (3, True, (40, 90), 1e-6, 7, 0, 12), (3, False, (40, 90), 1e-6, 7, 0, 12), (3, True, (36, 100), 1e-4, 15, 2, 9)])
+def test_adaptive_weight_guidedf_2_and_3(api, orc, which, is_left, shape, eps, win, minD, numD):
+    H, W = shape
+    L, R = _colour_pair(H * 5 + W + which, H, W, minD + numD // 2)
+    f = api.stereomatch_1.computeAdaptiveWeight_GuidedF_2 if which == 2 else api.stereomatch_1.computeAdaptiveWeight_GuidedF_3
+    got = f(L, R, api.DISPARITY_LEFT if is_left else api.DISPARITY_RIGHT, eps, win, minD, numD)
+    exp = orc.adaptive_weight_guidedf_23(L, R, which, is_left, eps, win, minD, numD)
+    # float winner-take-all over filtered slices: only near-ties may differ (eps = 1e-6 amplifies last-bit differences of the
+    # variance, so the third matcher gets a wider share)
+    _near_tie_check(got, exp, 0.003 if which == 2 else 0.02)
+    if which == 2:
+        assert (got[:, minD + numD:] == minD + numD // 2).mean() > 0.7
+
+
+def test_stereo_matching_dispatches_guided_filter_2_and_3(api, orc):
+    H, W = 40, 240
+    L, R = _colour_pair(21, H, W, 30)
+    _near_tie_check(api.stereoMatching(L, R, api.ADAPTIVE_WEIGHT_GUIDED_FILTER_2), orc.adaptive_weight_guidedf_23(L, R, 2, True, 0.01, 13, 10, 150))
+    _near_tie_check(api.stereoMatching(L, R, api.ADAPTIVE_WEIGHT_GUIDED_FILTER_3), orc.adaptive_weight_guidedf_23(L, R, 3, True, 1e-6, 15, 0, 64), 0.02)
+    from cameracalibration_amd._lib import MdispError
+    with pytest.raises(MdispError):
+        api.stereomatch_1.computeAdaptiveWeight_GuidedF_2(L, R, api.DISPARITY_RIGHT, 0.01, 7, 0, 8)

@@ -43,7 +43,7 @@ def test_cv_adapter_names_every_boundary_function():
                  "getGuidedFilter", "getGuidedFilter_wgif", "getGuidedFilter_egif", "getGuidedFilter_skwgif2", "getGuidedFilter_ours_gif", "getGuidedFilter_ours_gif2",
                  "getGuidedFilter_ours_gif3", "steerFilter",
                  "getDisparity_SGBM", "getDisparity_BM", "stereoMatching", "StereoBM", "postProcess_", "StereoMatchParam", "computeNCC",
-                 "getCostSAD_d", "computeAdaptiveWeight_GuidedF"):
+                 "getCostSAD_d", "computeAdaptiveWeight_GuidedF", "computeSimilarity", "computeAdaptiveWeight_GuidedF_2", "computeAdaptiveWeight_GuidedF_3"):
         assert name in text
 
 
@@ -73,11 +73,15 @@ def test_host_layer_outputs_match_oracle(orc, tmp_path):
     fL = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
     fR = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
     dGf = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
-    cSad = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
+    cSad = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    sim3 = buf[o:o + 4 * n].view(np.float32).reshape(H, W); o += 4 * n
+    dGf2 = buf[o:o + 4 * n].view(np.float32).reshape(H, W)
     Lc = np.stack([(L.astype(np.int32) * (4 - c) // 4).astype(np.uint8) for c in range(3)], axis=-1)
     Rc = np.stack([(R.astype(np.int32) * (4 - c) // 4).astype(np.uint8) for c in range(3)], axis=-1)
     eGf = orc.adaptive_weight_guidedf(Lc, Rc, True, 0.01, 7, 0, 12)
     assert (dGf != eGf).mean() < 2e-3                 # float winner-take-all: near-ties may differ
+    assert np.array_equal(sim3, orc.compute_similarity(Lc, Rc, True, 0.4, 10, 50, 0, 6)[3])
+    assert (dGf2 != orc.adaptive_weight_guidedf_23(Lc, Rc, 2, True, 0.01, 7, 0, 12)).mean() < 3e-3
     assert np.array_equal(cSad, orc.cost_sad_d(L, np.pad(R, ((0, 0), (8, 0)), mode="symmetric"), 3, True, 5))
     eL, eR = orc.postProcess_(L, R, dO, dO)
     assert np.abs(fL - eL).max() <= 1e-3 * max(1.0, float(np.abs(eL).max())) and np.abs(fR - eR).max() <= 1e-3 * max(1.0, float(np.abs(eR).max()))
