@@ -90,6 +90,16 @@ __device__ unsigned long long g_trace[SGM3_TRACE_MAX][6];      // per ticket: st
 // they travel with write-through stores and cache-bypassing loads like the hand-off rows, and a first-sweep band marks
 // itself done when all its stores have completed.
 constexpr int sgm3_state_dwords(int lpc, int nrt, bool s16) { return (s16 ? nrt : nrt / 2) * lpc; }
+// One wait state between a 16-byte buffer store whose scalar offset is a register and the next vector instruction that
+// overwrites one of its data registers.  The compiler leaves none for this form of the store (it does for an immediate
+// scalar offset), and without it the stored dword can be the NEW register contents.  Measured with a 16-byte store of
+// packed matching costs followed directly by the computation of the next column index into its first data register:
+// the first dword of lanes 12-15 of every sixteen arrived in memory as that column index, on a loaded GPU only (nine or
+// more full-size pairs in flight, never with four).  The data registers are operands of the statement, so they stay
+// allocated up to it.  (Also tried with that store: keeping the matching costs of the first sweep in memory for the
+// second one, 35 vector instructions fewer per second-sweep step -- bit-exact and SLOWER, 0.83 against 0.75 ms per
+// pair at 64 pairs: the extra byte per candidate written and read takes the kernel to the memory system's limit.)
+#define STORE_DATA_GUARD(d) asm volatile("s_nop 0" ::"v"((d).x), "v"((d).y), "v"((d).z), "v"((d).w) : "memory")
 template <bool UP, int ROLE, bool TAIL, bool S4B, int LPC, int NRT, int NT, bool S16, bool FOUR, bool COH>
 __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band, const int pair,
                                                u32 (*st)[NT / LPC + 1][3][sgm3_state_dwords(LPC, NRT, S16)], u32 (*srow)[LPC * NRT],
@@ -272,6 +282,7 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
         if constexpr (COH) {
             md_v4u d = {v.x, v.y, v.z, v.w};
             __builtin_amdgcn_raw_buffer_store_b128(d, srsrc, (int)off, (int)sRowBase, 18);
+            STORE_DATA_GUARD(d);
         } else store16_stream(Sbase + off, v);
     };
     u32 tail[NRT];
@@ -681,6 +692,7 @@ __device__ __forceinline__ void sgm3_ring_body(const RowArgs& ra, const int band
         if constexpr (COH) {
             md_v4u d = {val.x, val.y, val.z, val.w};
             __builtin_amdgcn_raw_buffer_store_b128(d, srsrc, (int)off, (int)sRowBase, 18);
+            STORE_DATA_GUARD(d);
         } else store16_stream(Sbase + off, val);
     };
     u32 tail[NRT];
