@@ -71,8 +71,21 @@ def measured_issue_bound():
         return None
     with open(files[-1]) as f:
         d = json.load(f)
-    return {"valu_wave_instructions_per_pair": d["valu_instructions_per_pair"], "ms_per_pair_at_full_issue": d["issue_bound_ms_per_pair"],
-            "source": os.path.relpath(files[-1], ROOT)}
+    out = {"valu_wave_instructions_per_pair": d["valu_instructions_per_pair"], "ms_per_pair_at_full_issue": d["issue_bound_ms_per_pair"],
+           "source": os.path.relpath(files[-1], ROOT)}
+    # where the per-opcode pricing exists (scripts/issue_bound.py: instructions of the main loops by opcode x the issue
+    # cost measured for each opcode, at the kernel's own clock, scaled to the counted instructions), it replaces the
+    # flat four cycles per instruction
+    priced = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sgm_issue_bound.json")))
+    if priced:
+        with open(priced[-1]) as f:
+            b = json.load(f)
+        if "ms_per_pair_scaled_to_counted_instructions" in b:
+            out["ms_per_pair_flat_4_cycles"] = out["ms_per_pair_at_full_issue"]
+            out["ms_per_pair_at_full_issue"] = b["ms_per_pair_scaled_to_counted_instructions"]
+            out["pricing"] = "sum over opcodes of count x measured issue cycles at %.2f GHz" % b["kernel_clock_ghz"]
+            out["source"] = os.path.relpath(priced[-1], ROOT)
+    return out
 
 
 def side_path(args):

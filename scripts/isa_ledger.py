@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Instruction ledger of the headline SGM kernels from the compiler's listing (hipcc -S of sgm3.hip, gfx950).
+"""Instruction ledger of the headline SGM kernel from the compiler's listing (hipcc -S of sgm3.hip, gfx950).
 
-For the D = 256 row-band kernels (first sweep; second sweep with the winner-take-all) it takes the main loop of the compute
-waves (the largest loop of the kernel: two steps, i.e. two pixels per slot), counts its instructions by opcode and groups the
+For the D = 256 one-launch row-band kernel (first sweep; second sweep with the winner-take-all) it takes the main loops of
+the compute waves (two steps, i.e. two pixels per slot, per iteration), counts their instructions by opcode and groups the
 opcodes by what they are used for in these kernels.  One wave-step handles 4 pixels x 256 disparities.
 
     python scripts/isa_ledger.py [out_prefix]      # writes <out_prefix>.json and <out_prefix>.txt (default profiles/sgm_isa_ledger)
@@ -16,9 +16,12 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the one-launch kernel holds four copies of the sweep body (down / up x first / second sweep): its compute-wave loops are
+# the loops of more than 500 instructions; the second sweep's are the ones with the winner-take-all's packed multiply-add
+MEET = "sgm3_meet_kernelILb0ELi16ELi8ELi256EEEvNS_7RowArgsE"
 KERNELS = {
-    "first sweep (stores the four-path sum)": "sgm3_rows_kernelILb0ELi0ELb0ELb1ELi16ELi8ELi256ELb0ELb0EEEv",
-    "second sweep + winner-take-all": "sgm3_rows_kernelILb1ELi1ELb0ELb1ELi16ELi8ELi256ELb0ELb0EEEv",
+    "first sweep (stores the four-path sum)": (MEET, False),
+    "second sweep + winner-take-all": (MEET, True),
 }
 GROUPS = [
     ("packed minimum (recursion: neighbours, three-input minimum; minimum trees of the paths and of the winner-take-all)",
@@ -45,8 +48,8 @@ def main():
                                os.path.join(ROOT, "cameracalibration_amd", "csrc", "sgm3.hip"), "-o", asm], stderr=subprocess.DEVNULL)
         lines = open(asm).read().split("\n")
     report, text = {}, []
-    for title, tag in KERNELS.items():
-        start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and tag in l and l.rstrip().split(":")[0].endswith("E"))
+    for title, (tag, second) in KERNELS.items():
+        start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and tag in l and l.split(":")[0].endswith("E"))
         end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = lines[start:end]
         labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
@@ -55,13 +58,18 @@ def main():
             m = re.search(r"\s(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
             if m and m.group(2) in labels and labels[m.group(2)] < i:
                 loops.append((i - labels[m.group(2)], labels[m.group(2)], i))
-        _, a, b = max(loops)
+        big = [(n, a, b) for n, a, b in loops if n > 500 and not any(a <= a2 and b2 <= b and (a2, b2) != (a, b) and n2 > 500 for n2, a2, b2 in loops)]
+        big = [(n, a, b) for n, a, b in big if sum("v_pk_minimum3_f16" in l for l in body[a:b + 1]) >= 50]      # (not the communication wave's)
+        big = [(n, a, b) for n, a, b in big if any("v_pk_mad_u16" in l for l in body[a:b + 1]) == second]
+        assert big, "no main loop found for " + title
         ops = collections.Counter()
-        for l in body[a:b + 1]:
-            l = l.strip()
-            if not l or l[0] in ";." or l.split()[0].endswith(":"):
-                continue
-            ops[l.split()[0]] += 1
+        for _, a, b in big:                     # the down and the up copy: averaged
+            for l in body[a:b + 1]:
+                l = l.strip()
+                if not l or l[0] in ";." or l.split()[0].endswith(":"):
+                    continue
+                ops[l.split()[0]] += 1
+        ops = collections.Counter({o: c / len(big) for o, c in ops.items()})
         groups = collections.OrderedDict((g, 0) for g, _ in GROUPS)
         groups["other"] = 0
         for op, c in ops.items():
@@ -77,12 +85,12 @@ def main():
             m = re.match(r";\s*(NumVgprs|ScratchSize|LDSByteSize|Occupancy):\s*(\d+)", l)
             if m:
                 regs[m.group(1)] = int(m.group(2))
-        report[title] = {"kernel": tag, "steps_per_loop_iteration": 2, "instructions_per_step": sum(ops.values()) / 2, "valu_per_step": valu / 2,
+        report[title] = {"kernel": tag, "loops_averaged": len(big), "steps_per_loop_iteration": 2, "instructions_per_step": sum(ops.values()) / 2, "valu_per_step": valu / 2,
                          "by_use_per_step": {g: c / 2 for g, c in groups.items()}, "by_opcode_per_two_steps": dict(ops.most_common()), **regs}
         text.append(f"{title}\n  {tag}\n  {regs}\n  per step of one wave (4 pixels x 256 disparities): {sum(ops.values()) / 2:.1f} instructions, {valu / 2:.1f} VALU")
         for g, c in groups.items():
             text.append(f"    {c / 2:7.1f}  {g}")
-        text.append("  opcodes (two steps): " + ", ".join(f"{o} {c}" for o, c in ops.most_common()))
+        text.append("  opcodes (two steps): " + ", ".join(f"{o} {c:g}" for o, c in ops.most_common()))
         text.append("")
     with open(out + ".json", "w") as f:
         json.dump(report, f, indent=1)
