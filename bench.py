@@ -100,9 +100,12 @@ def side_summary():
     out = {}
     for name, path, hh in (("stereosgbm_1920x1080_D256_mode_sgbm", "stereosgbm", False), ("stereosgbm_1920x1080_D256_mode_hh", "stereosgbm", True),
                            ("census_box_wta_640x480_D64", "census_box", False)):
-        a = argparse.Namespace(path=path, disp=256, paths=8, hh=hh, steps=10, warmup=3)
+        a = argparse.Namespace(path=path, disp=256, paths=8, hh=hh, steps=10, warmup=3, pairs_per_call=1)
         r = measure_side(a)
         out[name] = {"ms_per_call": r["ms_per_step"], "Mdisp_per_s": r["value"], "workload": r["config"]["workload"]}
+    a = argparse.Namespace(path="stereosgbm", disp=256, paths=8, hh=False, steps=4, warmup=1, pairs_per_call=8)
+    r = measure_side(a)
+    out["stereosgbm_1920x1080_D256_mode_sgbm_batch_of_8"] = {"ms_per_pair": r["ms_per_step"] / 8, "Mdisp_per_s": r["value"], "workload": r["config"]["workload"]}
     return out
 
 
@@ -128,6 +131,20 @@ def measure_side(args):
 
         def step():
             _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), h, w, 1, w, C.byref(prm), out.data_ptr(), ws.data_ptr(), nb))
+        nbatch = getattr(args, "pairs_per_call", 1)
+        if nbatch > 1:
+            # mdisp_stereosgbm_batch_dev: the same pair nbatch times (distinct outputs), pairs side by side on the context's streams
+            dl, dr = dl.unsqueeze(0).repeat(nbatch, 1, 1).contiguous(), dr.unsqueeze(0).repeat(nbatch, 1, 1).contiguous()
+            out = torch.empty((nbatch, h, w), dtype=torch.int16, device="cuda")
+            nb = lib.mdisp_stereosgbm_batch_workspace_bytes(h, w, 1, C.byref(prm), nbatch)
+            ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            workload = workload.replace("one pair per call", f"{nbatch} pairs per call")
+            alg *= nbatch
+
+            def step():
+                _lib.check(lib.mdisp_stereosgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), nbatch, h * w, h, w, 1, w, C.byref(prm),
+                                                          out.data_ptr(), ws.data_ptr(), nb))
     else:
         h, w, d = 480, 640, 64
         prm = _lib.mdisp_param(7, 0, d - 1, 1)
@@ -151,7 +168,7 @@ def measure_side(args):
     elapsed = time.perf_counter() - t0
     per = elapsed / args.steps
     return ({
-        "metric": f"Mdisp/s (WxHxD per sec) at {w}x{h}, D={d}", "value": w * h * d / per / 1e6, "unit": "Mdisp/s", "n_gpus": 1,
+        "metric": f"Mdisp/s (WxHxD per sec) at {w}x{h}, D={d}", "value": w * h * d * getattr(args, "pairs_per_call", 1) / per / 1e6, "unit": "Mdisp/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "s16" if args.path == "stereosgbm" else "u16", "data": "synthetic",
         "config": {"workload": workload, "path": args.path},
@@ -177,6 +194,7 @@ def main():
     ap.add_argument("--path", default="sgm", choices=["sgm", "stereosgbm", "census_box"],
                     help="sgm: the headline configuration; stereosgbm / census_box: side measurements of the cv::StereoSGBM "
                          "replacement at 1920x1080 and of census + box + WTA at 640x480 (one GPU, one pair per call)")
+    ap.add_argument("--pairs-per-call", type=int, default=1, help="--path stereosgbm: pairs per mdisp_stereosgbm_batch_dev call (1: the single-pair entry point)")
     ap.add_argument("--hh", action="store_true", help="--path stereosgbm: MODE_HH (eight directions) instead of MODE_SGBM")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed batch with the single-pair call "
                     "(counter passes: the single-pair call's kernels would be counted with the batch's)")

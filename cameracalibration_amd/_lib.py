@@ -20,7 +20,8 @@ E_BADARG, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_RANGE, E_NOMEM = -1, -2, -3, -4, -
 # keys of mdisp_tuning_set (include/mdisp.h)
 (TUNE_SGM_SPLIT_MAX, TUNE_SGM_PATH_WAVES_MAX, TUNE_SGM_STRIP_LANES, TUNE_SGM_FORCE_PREPASS, TUNE_SGM_LANES16,
  TUNE_SGM_PER_DIRECTION, TUNE_SGBM_BT_SEQUENTIAL, TUNE_SGM_PIPELINE, TUNE_SGM_PLANT_ERROR, TUNE_SGM_BAND_SLACK, TUNE_SGM_PAIR_GROUP,
- TUNE_SGM_HAND_RING, TUNE_SGM_MEET_MAX, TUNE_SGM_ONE_LAUNCH, TUNE_SAT_INT_TABLES, TUNE_SGM_RING_HANDOFF, TUNE_COUNT) = range(17)
+ TUNE_SGM_HAND_RING, TUNE_SGM_MEET_MAX, TUNE_SGM_ONE_LAUNCH, TUNE_SAT_INT_TABLES, TUNE_SGM_RING_HANDOFF, TUNE_SGBM_BATCH_LANES,
+ TUNE_COUNT) = range(18)
 
 
 class mdisp_image(C.Structure):
@@ -59,7 +60,7 @@ EXPORTS = [
     "mdisp_sgbm_batch_workspace_bytes", "mdisp_sgbm_batch_dev", "mdisp_sgbm_rows_geometry", "mdisp_sgbm_rows_sweep_dev",
     "mdisp_census_stereo_dev", "mdisp_asw_gifs_band_dev", "mdisp_last_kernel_ms", "mdisp_enable_timing", "mdisp_synth_pair",
     "mdisp_stereosgbm_compute", "mdisp_stereosgbm_stages", "mdisp_median_blur3_s16", "mdisp_filter_speckles_s16",
-    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity", "mdisp_ncc",
+    "mdisp_stereosgbm_workspace_bytes", "mdisp_stereosgbm_dev", "mdisp_stereosgbm_batch_workspace_bytes", "mdisp_stereosgbm_batch_dev", "mdisp_sgbm_batch", "mdisp_legacy_disparity", "mdisp_ncc",
     "mdisp_asw_gifs_band_stats_dev", "mdisp_rectify_maps_create", "mdisp_rectify_maps_destroy", "mdisp_rectify_maps_download", "mdisp_remap_with", "mdisp_remap_dev",
     "mdisp_census_stereo_dev_noalloc", "mdisp_create_on_stream", "mdisp_tuning_set", "mdisp_tuning_get",
     "mdisp_copy_bandwidth_dev", "mdisp_stereobm_compute", "mdisp_stereobm_workspace_bytes", "mdisp_stereobm_dev", "mdisp_fgs_filter",
@@ -124,6 +125,9 @@ def load():
     lib.mdisp_stereosgbm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, ssp]
     lib.mdisp_stereosgbm_workspace_bytes.restype = C.c_size_t
     lib.mdisp_stereosgbm_dev.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_size_t, ssp, vp, vp, C.c_size_t]
+    lib.mdisp_stereosgbm_batch_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, ssp, C.c_int]
+    lib.mdisp_stereosgbm_batch_workspace_bytes.restype = C.c_size_t
+    lib.mdisp_stereosgbm_batch_dev.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_size_t, ssp, vp, vp, C.c_size_t]
     dp = C.POINTER(C.c_double)
     lib.mdisp_rectify_maps_create.argtypes = [vp, dp, dp, C.c_int, dp, dp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.mdisp_rectify_maps_destroy.argtypes = [vp]

@@ -78,7 +78,7 @@ static int create_ctx(mdisp_ctx** out, int device, void* stream, bool useGiven)
     if (hipSetDevice(device) != hipSuccess) { mdisp_set_error("hipSetDevice(%d) failed", device); return MDISP_E_NODEVICE; }
     mdisp_ctx* c = new (std::nothrow) mdisp_ctx();
     MD_REQUIRE(c, MDISP_E_NOMEM, "out of host memory");
-    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_pending = false; c->aux = nullptr; c->aux_ready = false; c->stage = nullptr; c->stage_bytes = 0;
+    c->device = device; c->ws = nullptr; c->ws_bytes = 0; c->timing = false; c->sgm_err = nullptr; c->sgm_pending = false; c->aux = nullptr; c->aux_ready = false; c->lanes_ready = false; c->stage = nullptr; c->stage_bytes = 0;
     for (int i = 0; i < 3; i++) c->ev_valid[i] = false;
     if (useGiven) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -114,6 +114,10 @@ extern "C" void mdisp_destroy(mdisp_ctx* c)
         (void)hipStreamSynchronize(c->aux);
         for (int i = 0; i < 3; i++) (void)hipEventDestroy(c->aux_ev[i]);
         (void)hipStreamDestroy(c->aux);
+    }
+    if (c->lanes_ready) {
+        for (int i = 0; i < 3; i++) { (void)hipStreamSynchronize(c->lane[i]); (void)hipStreamDestroy(c->lane[i]); }
+        for (int i = 0; i < 4; i++) (void)hipEventDestroy(c->lane_ev[i]);
     }
     if (c->stage) (void)hipFree(c->stage);
     if (c->sgm_err) (void)hipFree(c->sgm_err);
@@ -1008,6 +1012,61 @@ extern "C" int mdisp_stereosgbm_dev(mdisp_ctx* c, const uint8_t* dL, const uint8
     if (ws) MD_REQUIRE(ws_bytes >= need, MDISP_E_NOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
     else if (!(ws = mdisp_ws(c, need))) return MDISP_E_NOMEM;
     return md_stereosgbm_run(c->stream, dL, dR, pitch, rows, cols, channels, p, dDisp, ws, nullptr, nullptr);
+}
+
+// Pairs of a batch side by side: a single pair's launches are partly bound by the serial chains of their scan lines
+// (a horizontal direction has one line per image row: about one wave per SIMD) and partly by memory, so up to
+// MD_SGBM_LANES pairs run at once, each on a stream and in a workspace slice of its own, and fill each other's gaps.
+#define MD_SGBM_LANES 4
+static int sgbm_lanes(int n)
+{
+    const int t = md_tune(MDISP_TUNE_SGBM_BATCH_LANES);
+    const int lanes = t > 0 ? (t < MD_SGBM_LANES ? t : MD_SGBM_LANES) : MD_SGBM_LANES;
+    return n < lanes ? n : lanes;
+}
+extern "C" size_t mdisp_stereosgbm_batch_workspace_bytes(int rows, int cols, int channels, const mdisp_stereosgbm_params* p, int n_pairs)
+{
+    if (!p || rows <= 0 || cols <= 0 || n_pairs <= 0 || p->numDisparities <= 0 || p->minDisparity < 0) return 0;
+    const int lanes = n_pairs < MD_SGBM_LANES ? n_pairs : MD_SGBM_LANES;
+    return md_align(md_stereosgbm_bytes(rows, cols, channels, p), 256) * lanes;
+}
+
+extern "C" int mdisp_stereosgbm_batch_dev(mdisp_ctx* c, const uint8_t* dL, const uint8_t* dR, int n_pairs, size_t pair_stride_bytes,
+                                          int rows, int cols, int channels, size_t pitch, const mdisp_stereosgbm_params* p,
+                                          int16_t* dDisp, void* ws, size_t ws_bytes)
+{
+    MD_REQUIRE(c && dL && dR && dDisp && p, MDISP_E_BADARG, "null argument");
+    MD_REQUIRE(n_pairs > 0 && rows > 0 && cols > 0 && (channels == 1 || channels == 3) && pitch >= (size_t)cols * channels &&
+               pair_stride_bytes >= pitch * rows, MDISP_E_BADARG, "bad geometry");
+    MD_REQUIRE(p->numDisparities > 0 && p->minDisparity >= 0, MDISP_E_BADARG, "bad disparity range");
+    MD_HIP(hipSetDevice(c->device));
+    const size_t one = md_align(md_stereosgbm_bytes(rows, cols, channels, p), 256);
+    const size_t need = mdisp_stereosgbm_batch_workspace_bytes(rows, cols, channels, p, n_pairs);
+    if (ws) MD_REQUIRE(ws_bytes >= need, MDISP_E_NOMEM, "workspace too small: %zu < %zu", ws_bytes, need);
+    else if (!(ws = mdisp_ws(c, need))) return MDISP_E_NOMEM;
+    const int lanes = sgbm_lanes(n_pairs);
+    if (lanes > 1 && !c->lanes_ready) {
+        for (int i = 0; i < 3; i++) MD_HIP(hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking));
+        for (int i = 0; i < 4; i++) MD_HIP(hipEventCreateWithFlags(&c->lane_ev[i], hipEventDisableTiming));
+        c->lanes_ready = true;
+    }
+    // the other lanes start after everything enqueued on the context's stream so far, and the stream continues after them
+    if (lanes > 1) {
+        MD_HIP(hipEventRecord(c->lane_ev[0], c->stream));
+        for (int l = 1; l < lanes; l++) MD_HIP(hipStreamWaitEvent(c->lane[l - 1], c->lane_ev[0], 0));
+    }
+    int rc = MDISP_OK;
+    for (int i = 0; i < n_pairs && rc == MDISP_OK; i++) {
+        const int l = i % lanes;
+        rc = md_stereosgbm_run(l == 0 ? c->stream : c->lane[l - 1], dL + (size_t)i * pair_stride_bytes, dR + (size_t)i * pair_stride_bytes, pitch,
+                               rows, cols, channels, p, dDisp + (size_t)i * rows * cols, (u8*)ws + (size_t)l * one, nullptr, nullptr);
+    }
+    // joined even after a failure, so that the context's stream never runs ahead of work already enqueued on a lane
+    for (int l = 1; l < lanes; l++) {
+        MD_HIP(hipEventRecord(c->lane_ev[l], c->lane[l - 1]));
+        MD_HIP(hipStreamWaitEvent(c->stream, c->lane_ev[l], 0));
+    }
+    return rc;
 }
 
 extern "C" size_t mdisp_stereobm_workspace_bytes(int rows, int cols, const mdisp_stereobm_params* p)

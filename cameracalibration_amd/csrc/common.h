@@ -56,6 +56,9 @@ struct mdisp_ctx {
     bool aux_ready;
     int* sgm_err;        // device word owned by the context: set (never cleared) by a pipelined SGM kernel whose hand-off wait ran out
     bool sgm_pending;    // a pipelined SGM call has been enqueued since the word was last read
+    hipStream_t lane[3]; // further streams of the batched StereoSGBM entry point (pairs side by side; created on first use)
+    hipEvent_t lane_ev[4];
+    bool lanes_ready;
     u8* noalloc_scratch; // device address, on this context's GPU, of the file-scope scratch array of the no-allocation entry point
 };
 // after the stream has been synchronised: fails if the last SGM call reported a hand-off timeout

@@ -283,6 +283,8 @@ struct PathArgs {
     int mdx[4], mdy[4], mfirst[5];        // MULTI: the directions of one launch and the first line index of each
     const void* accIn;                    // the group's sum so far (read); `acc` receives the new sum
     void* opp;                            // OPP: the path values of the direction opposite to the launch's own
+    // SEL: the last direction of the last group selects the pixel's disparity instead of storing S
+    u32* key; uint2* rec; int W, minX1, minD, q;      // q = 100 - uniquenessRatio
 };
 
 // cross-lane moves on the DPP path (no LDS crossbar round trip in the serial recursion)
@@ -311,9 +313,31 @@ __device__ __forceinline__ int wave_min_dpp(int v)
 // the time of its serial chain whatever else runs.  With FIRST, the launch therefore runs the opposite direction as well, on
 // as many more waves (lines nlines .. 2 * nlines - 1), and keeps its path values in `opp`.  With LAST, `opp` is added
 // after the group's own sum: S = saturate(saturate(S + acc + L) + opp), the sum the next group would have formed.
-template <int ND, bool FIRST, bool LAST = false, class AccT = int, bool MULTI = false, bool OPP = false>
+// SEL (with LAST, for the vertical and diagonal directions: thousands of lines, bound by memory and not by the chain of a
+// line): the wave that completes a pixel's sums S holds all of them in its lanes, so it selects on the spot what
+// bt_select_kernel would read S back for -- first-minimum winner, uniqueness test, the candidate for the right view's map
+// (a 32-bit atomic minimum per pixel, order-independent) and the two neighbours of the minimum for the parabola -- and
+// writes an 8-byte record per pixel; S is never stored (2 bytes per candidate written and read back saved).
+// bt_finish_kernel turns the records into the map.
+// PK (16-bit group sums, at least two candidates per lane): the recursion itself runs on packed pairs of 16-bit values --
+// the costs and the group sums are packed pairs in memory already, so nothing is unpacked or packed on the way.  Legal
+// whenever the 16-bit group sums are (3 * max(Cmax, P2) <= 32767): every path value lies in [-P2, Cmax], minL + P2 in
+// [0, Cmax + P2], so no 16-bit operation wraps; only "SHRT_MAX + P1" of the candidates beyond the range must not, and that
+// addition saturates.  Only the direction that completes S widens its values (the library's saturation points).
+typedef short bt_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_min_s16(u32 a, u32 b)
+{ return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(bt_s2, a), __builtin_bit_cast(bt_s2, b))); }
+__device__ __forceinline__ u32 pk_add_s16(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(bt_s2, a) + __builtin_bit_cast(bt_s2, b)); }
+__device__ __forceinline__ u32 pk_sub_s16(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(bt_s2, a) - __builtin_bit_cast(bt_s2, b)); }
+__device__ __forceinline__ u32 pk_add_sat_s16(u32 a, u32 b)
+{ return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(bt_s2, a), __builtin_bit_cast(bt_s2, b))); }
+
+template <int ND, bool FIRST, bool LAST = false, class AccT = int, bool MULTI = false, bool OPP = false, bool SEL = false, bool PK = false>
 __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy, int nlines)
 {
+    static_assert(!PK || (ND >= 2 && sizeof(AccT) == 2 && !MULTI), "packed recursion: 16-bit group sums, pairs of candidates per lane");
+    constexpr int NP = ND >= 2 ? ND / 2 : 1;
+    constexpr u32 SENT2 = 0x7FFF7FFFu;
     AccT* accp = static_cast<AccT*>(a.acc);
     const AccT* const accInp = static_cast<const AccT*>(a.accIn);
     // every element of S is read (several steps ahead) and later written by the same lane and by nobody else
@@ -345,6 +369,10 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     int Lp[ND];
 #pragma unroll
     for (int j = 0; j < ND; j++) Lp[j] = mine ? 0 : 32767;    // L_r(., -1) = L_r(., D) = SHRT_MAX
+    u32 Pp[NP];                               // PK: the same as packed pairs [candidate 2i | candidate 2i + 1]
+#pragma unroll
+    for (int i = 0; i < NP; i++) Pp[i] = mine ? 0u : SENT2;
+    const u32 P1P1 = (u32)a.P1 | ((u32)a.P1 << 16);
     int minPrev = 0;
     const int P1 = a.P1, P2 = a.P2;
     typedef typename CVec<ND>::type V;
@@ -365,6 +393,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         in.c = bt_ld(reinterpret_cast<const V*>(a.C + o));
         if (!FIRST) in.old = bt_ld(reinterpret_cast<const AV*>(accInp + o));
         if (LAST && !a.firstGroup) in.sOld = bt_ld(reinterpret_cast<const V*>(Sin + o));
+        static_assert(!SEL || (LAST && !MULTI), "selection belongs to the direction that completes S");
         if (OPP && LAST) in.opp = bt_ld(reinterpret_cast<const AV*>(static_cast<const AccT*>(a.opp) + o));
     };
 #pragma unroll
@@ -382,18 +411,47 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
             for (int j = 0; j < ND; j++) old[j] = (int)oldv[j];
         }
-        const int left = wave_shr1(Lp[ND - 1], 32767);
-        const int right = wave_shl1(Lp[0], 32767);
         const int delta = minPrev + P2;
         int Ln[ND], mn = BT_BIG;
+        [[maybe_unused]] u32 Lw[NP];
+        if constexpr (PK) {
+            u32 cw[NP];
+            __builtin_memcpy(cw, &in.c, sizeof(V));
+            // n[i] = [candidate 2i - 1 | candidate 2i]: the lower neighbours of pair i and the upper neighbours of pair i - 1
+            const u32 left = (u32)wave_shr1((int)Pp[NP - 1], (int)SENT2), right = (u32)wave_shl1((int)Pp[0], (int)SENT2);
+            u32 nb[NP + 1];
+            nb[0] = __builtin_amdgcn_alignbit(Pp[0], left, 16);
 #pragma unroll
-        for (int j = 0; j < ND; j++) {
-            const int lo = j > 0 ? Lp[j - 1] : left, hi = j < ND - 1 ? Lp[j + 1] : right;
-            int L = (int)c[j] + min(min(Lp[j], lo + P1), min(hi + P1, delta)) - delta;
-            L = (int)(int16_t)L;
-            if (!mine) L = BT_BIG;
-            Ln[j] = L;
-            mn = min(mn, L);
+            for (int i = 1; i < NP; i++) nb[i] = __builtin_amdgcn_alignbit(Pp[i], Pp[i - 1], 16);
+            nb[NP] = __builtin_amdgcn_alignbit(right, Pp[NP - 1], 16);
+            const u32 d2 = (u32)delta | ((u32)delta << 16);          // 0 <= delta <= 32767
+            u32 mn2 = SENT2;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const u32 t = pk_add_sat_s16(pk_min_s16(nb[i], nb[i + 1]), P1P1);
+                const u32 m = pk_min_s16(pk_min_s16(Pp[i], t), d2);
+                u32 L = pk_add_s16(pk_sub_s16(m, d2), cw[i]);
+                if (!mine) L = SENT2;
+                Lw[i] = L;
+                mn2 = pk_min_s16(mn2, L);
+            }
+            mn = min((int)(int16_t)(mn2 & 0xFFFFu), (int)mn2 >> 16);
+            if constexpr (LAST) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) { Ln[2 * i] = (int)(int16_t)(Lw[i] & 0xFFFFu); Ln[2 * i + 1] = (int)Lw[i] >> 16; }
+            }
+        } else {
+            const int left = wave_shr1(Lp[ND - 1], 32767);
+            const int right = wave_shl1(Lp[0], 32767);
+#pragma unroll
+            for (int j = 0; j < ND; j++) {
+                const int lo = j > 0 ? Lp[j - 1] : left, hi = j < ND - 1 ? Lp[j + 1] : right;
+                int L = (int)c[j] + min(min(Lp[j], lo + P1), min(hi + P1, delta)) - delta;
+                L = (int)(int16_t)L;
+                if (!mine) L = BT_BIG;
+                Ln[j] = L;
+                mn = min(mn, L);
+            }
         }
         mn = wave_min_dpp(mn);
         if (mine) {
@@ -412,13 +470,23 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
                     for (int j = 0; j < ND; j++) sv[j] = (int16_t)min(max((int)sv[j] + (int)ov[j], -32768), 32767);
                 }
-                V packed;
-                __builtin_memcpy(&packed, sv, sizeof(V));
-                bt_st(reinterpret_cast<V*>(Sout + o), packed);
+                if constexpr (!SEL) {
+                    V packed;
+                    __builtin_memcpy(&packed, sv, sizeof(V));
+                    bt_st(reinterpret_cast<V*>(Sout + o), packed);
+                }
             } else if (MULTI) {
                 int* ap = static_cast<int*>(a.acc) + o;
 #pragma unroll
                 for (int j = 0; j < ND; j++) atomicAdd(ap + j, Ln[j]);
+            } else if constexpr (PK) {
+                u32 aw[NP];
+                if (!FIRST) __builtin_memcpy(aw, &in.old, sizeof(AV));
+#pragma unroll
+                for (int i = 0; i < NP; i++) aw[i] = FIRST ? Lw[i] : pk_add_s16(aw[i], Lw[i]);
+                AV packedAcc;
+                __builtin_memcpy(&packedAcc, aw, sizeof(AV));
+                bt_st(reinterpret_cast<AV*>(accp + o), packedAcc);
             } else {
                 AccT av[ND];
 #pragma unroll
@@ -434,8 +502,62 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 }
             }
         }
+        if constexpr (SEL) {
+            // the pixel's sums once more, in every lane (lanes beyond D: excluded below)
+            int sv[ND];
+            {
+                int16_t so[ND];
+                if (!a.firstGroup) __builtin_memcpy(so, &in.sOld, sizeof(V));
+                AccT ov[ND];
+                if (OPP) __builtin_memcpy(ov, &in.opp, sizeof(AV));
 #pragma unroll
-        for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
+                for (int j = 0; j < ND; j++) {
+                    int v = (a.firstGroup ? 0 : (int)so[j]) + old[j] + Ln[j];
+                    v = min(max(v, -32768), 32767);
+                    if (OPP) v = min(max(v + (int)ov[j], -32768), 32767);
+                    sv[j] = v;
+                }
+            }
+            u32 best = 0xFFFFFFFFu;
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < ND; j++) best = min(best, ((u32)(sv[j] + 32768) << 16) | (u32)(k0 + j));
+            }
+            best = (u32)wave_min_dpp((int)(best ^ 0x80000000u)) ^ 0x80000000u;
+            const int bk = (int)(best & 0xFFFF), minS = (int)(best >> 16) - 32768;
+            const int lim = minS * 100;
+            bool bad = false;
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < ND; j++) bad |= (__mul24(sv[j], a.q) < lim) && ((u32)(k0 + j - bk + 1) > 2u);
+            }
+            const bool rejected = __any(bad);
+            // S(best - 1), S(best + 1): every lane lines up the neighbours of its own candidates (the edge ones come from the
+            // neighbouring lanes through the cross-lane network), and the lane that owns the winner writes the pixel's record
+            const int e = bk - k0;
+            const int left = wave_shr1(sv[ND - 1], 0), right = wave_shl1(sv[0], 0);
+            int sm = left, spl = ND > 1 ? sv[1] : right;
+#pragma unroll
+            for (int j = 1; j < ND; j++) {
+                sm = e == j ? sv[j - 1] : sm;
+                spl = e == j ? (j + 1 < ND ? sv[j + 1] : right) : spl;
+            }
+            if ((u32)e < (u32)ND) {
+                const int yy = y0 + t * dy, x = x0 + t * dx + a.minX1;
+                uint2 rec;
+                rec.x = rejected ? 0xFFFFFFFFu : best;
+                rec.y = ((u32)sm & 0xFFFFu) | ((u32)spl << 16);
+                a.rec[(size_t)yy * a.W + x] = rec;
+                if (!rejected) atomicMin(&a.key[(size_t)yy * a.W + (x - bk - a.minD)], ((best >> 16) << 16) | (u32)(0xFFFF - x));
+            }
+        }
+        if constexpr (PK) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) Pp[i] = Lw[i];
+        } else {
+#pragma unroll
+            for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
+        }
         minPrev = mn;
     };
     // whole groups of PF steps run without an exit in the middle (an early exit makes the compiler rotate the ring through
@@ -563,6 +685,49 @@ __global__ __launch_bounds__(BT_SEL_THREADS) void bt_select_kernel(SelArgs a)
             auto inconsistent = [&](int xx, int dd) -> bool {
                 if (xx < 0 || xx >= W) return false;
                 const u32 kk = key[xx];
+                const int d2 = (kk == 0xFFFFFFFFu) ? INVALID : (0xFFFF - (int)(kk & 0xFFFF)) - xx;
+                return d2 >= a.minD && abs(d2 - dd) > a.maxDiff;
+            };
+            const int _d = v >> 4, d_ = (v + 15) >> 4;
+            if (inconsistent(x - _d, _d) && inconsistent(x - d_, d_)) v = INVALID;
+        }
+        a.disp[(size_t)y * W + x] = (int16_t)v;
+    }
+}
+
+// The map from the records of a selecting last direction (SEL): the x16 parabola through the winner's neighbours, then the
+// disp12MaxDiff check against the right view's candidates (bt_select_kernel's last two passes).  One workgroup per image row.
+__global__ __launch_bounds__(256) void bt_finish_kernel(SelArgs a, const uint2* __restrict__ rec, const u32* __restrict__ key)
+{
+    extern __shared__ u32 lds[];
+    int* dsp = reinterpret_cast<int*>(lds);      // [W] disparity x16 of the row's pixels
+    const int y = blockIdx.x, W = a.W, D = a.D;
+    const int INVALID = (a.minD - 1) * 16;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int v = INVALID;
+        if (x >= a.minX1) {
+            const uint2 r = rec[(size_t)y * W + x];
+            if (r.x != 0xFFFFFFFFu) {
+                const int bk = (int)(r.x & 0xFFFF), s0 = (int)(r.x >> 16) - 32768;
+                int d = bk * 16;
+                if (bk > 0 && bk < D - 1) {
+                    const int sm = (int)(int16_t)(r.y & 0xFFFFu), spl = (int)(int16_t)(r.y >> 16);
+                    const int den = max(sm + spl - 2 * s0, 1);
+                    d += ((sm - spl) * 16 + den) / (den * 2);
+                }
+                v = (int)(int16_t)(d + a.minD * 16);
+            }
+        }
+        dsp[x] = v;
+    }
+    __syncthreads();
+    const u32* krow = key + (size_t)y * W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int v = dsp[x];
+        if (v != INVALID && x >= a.minX1) {
+            auto inconsistent = [&](int xx, int dd) -> bool {
+                if (xx < 0 || xx >= W) return false;
+                const u32 kk = krow[xx];
                 const int d2 = (kk == 0xFFFFFFFFu) ? INVALID : (0xFFFF - (int)(kk & 0xFFFF)) - xx;
                 return d2 >= a.minD && abs(d2 - dd) > a.maxDiff;
             };
@@ -712,7 +877,7 @@ size_t md_stereosgbm_bytes(int H, int W, int cn, const mdisp_stereosgbm_params* 
     const int D = p->numDisparities, W1 = W - p->minDisparity - D;
     const size_t N = (size_t)H * W, V = W1 > 0 ? (size_t)H * W1 * D : 0;
     return md_align(N * 2 * cn, 256) * 2 + md_align(V * 2, 256) * 3 + md_align(V * 4, 256) + md_align(N * 2, 256) * 2 +
-           md_speckle_scratch_bytes(H, W) + 4096;
+           md_speckle_scratch_bytes(H, W) + md_align(N * 4, 256) + md_align(N * 8, 256) + 4096;
 }
 
 static int validate(int H, int W, int cn, const mdisp_stereosgbm_params* p)
@@ -753,6 +918,7 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     int* acc = (int*)take(V * 4);
     int16_t* raw = (int16_t*)take(N * 2); int16_t* med = (int16_t*)take(N * 2);
     void* spk = take(md_speckle_scratch_bytes(H, W));
+    u32* selKey = (u32*)take(N * 4); uint2* selRec = (uint2*)take(N * 8);
     if (g.W1 <= 0) {
         // every column is left of minDisparity + numDisparities: the library returns an all-invalid map
         // (the median and speckle stages keep it constant)
@@ -790,6 +956,11 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
     // have wrapped either): block cost <= bs^2 * cn * (2 * ftzero + 255 / 4)
     const long cmax = (long)g.bs * g.bs * cn * (2 * g.ftzero + 63);
     const bool acc16 = 3 * std::max<long>(cmax, P2) <= 32767;
+    const int uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    pa.key = selKey; pa.rec = selRec; pa.W = W; pa.minX1 = g.minX1; pa.minD = g.minD; pa.q = 100 - uniq;
+    bool selected = false;        // the last direction has selected: records instead of S
+    // (MDISP_TUNE_SGBM_BT_SEQUENTIAL = 2 keeps the separate selection kernel on this schedule: the tests run both)
+    const bool selInLast = md_tune(MDISP_TUNE_SGBM_BT_SEQUENTIAL) != 2;
     for (int grp = 0; grp < 2; grp++) {
         const int ndir = (grp == 1 && p->mode == MDISP_SGBM_MODE_SGBM) ? 1 : 4;
         pa.firstGroup = grp == 0;
@@ -835,27 +1006,34 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             const bool oppLast = opp && grp == 0 && i == ndir - 1 && p->mode == MDISP_SGBM_MODE_SGBM;      // MODE_SGBM: <- is all of the second group
             pa.accIn = (opp && grp == 1 && i == 1) ? (const void*)v1 : (const void*)acc;
             if (oppFirst) gp = dim3((2 * nlines + 3) / 4);
-#define BT_PATH(NDV, ACC)                                                                                      \
+            // the direction that completes S (MODE_SGBM with <- folded in: the first group's last; MODE_HH: the second group's)
+            const bool sel = selInLast && ndir == 4 && i == ndir - 1 && (oppLast || (grp == 1 && p->mode == MDISP_SGBM_MODE_HH));
+            if (sel) { MD_HIP(hipMemsetAsync(selKey, 0xFF, N * 4, s)); selected = true; }
+#define BT_PATH(NDV, ACC, PKV)                                                                                 \
             do {                                                                                               \
-                if (oppFirst) bt_path_kernel<NDV, true, false, ACC, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);          \
-                else if (oppLast) bt_path_kernel<NDV, false, true, ACC, false, true><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);      \
-                else if (ndir == 1) bt_path_kernel<NDV, true, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
-                else if (i == 0) bt_path_kernel<NDV, true, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
-                else if (i == ndir - 1) bt_path_kernel<NDV, false, true, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
-                else bt_path_kernel<NDV, false, false, ACC><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                \
+                if (oppFirst) bt_path_kernel<NDV, true, false, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);          \
+                else if (oppLast && sel) bt_path_kernel<NDV, false, true, ACC, false, true, true, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
+                else if (sel) bt_path_kernel<NDV, false, true, ACC, false, false, true, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);   \
+                else if (oppLast) bt_path_kernel<NDV, false, true, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);      \
+                else if (ndir == 1) bt_path_kernel<NDV, true, true, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
+                else if (i == 0) bt_path_kernel<NDV, true, false, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
+                else if (i == ndir - 1) bt_path_kernel<NDV, false, true, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
+                else bt_path_kernel<NDV, false, false, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                \
             } while (0)
-            if (acc16) { if (nd == 1) BT_PATH(1, int16_t); else if (nd == 2) BT_PATH(2, int16_t); else if (nd == 4) BT_PATH(4, int16_t); else BT_PATH(8, int16_t); }
-            else { if (nd == 1) BT_PATH(1, int); else if (nd == 2) BT_PATH(2, int); else if (nd == 4) BT_PATH(4, int); else BT_PATH(8, int); }
+            // 16-bit group sums: the recursion on packed pairs (two candidates per lane at least)
+            if (acc16) { if (nd == 1) BT_PATH(1, int16_t, false); else if (nd == 2) BT_PATH(2, int16_t, true); else if (nd == 4) BT_PATH(4, int16_t, true); else BT_PATH(8, int16_t, true); }
+            else { if (nd == 1) BT_PATH(1, int, false); else if (nd == 2) BT_PATH(2, int, false); else if (nd == 4) BT_PATH(4, int, false); else BT_PATH(8, int, false); }
 #undef BT_PATH
         }
     }
     MD_HIP(hipGetLastError());
     SelArgs sa;
     sa.S = S; sa.H = H; sa.W = W; sa.W1 = g.W1; sa.D = g.D; sa.minD = g.minD; sa.minX1 = g.minX1;
-    sa.uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
+    sa.uniq = uniq;
     sa.maxDiff = p->disp12MaxDiff > 0 ? p->disp12MaxDiff : 1;
     sa.disp = raw;
-    if (nd == 1) bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
+    if (selected) bt_finish_kernel<<<H, 256, (size_t)W * 4, s>>>(sa, selRec, selKey);
+    else if (nd == 1) bt_select_kernel<1><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
     else if (nd == 2) bt_select_kernel<2><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
     else if (nd == 4) bt_select_kernel<4><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);
     else bt_select_kernel<8><<<H, BT_SEL_THREADS, (size_t)W * 8 + 16, s>>>(sa);

@@ -358,6 +358,16 @@ size_t mdisp_stereosgbm_workspace_bytes(int rows, int cols, int channels, const 
 int mdisp_stereosgbm_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int rows, int cols, int channels, size_t pitch,
                          const mdisp_stereosgbm_params* p, int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
 
+/* The same for n_pairs pairs (methods/methods.cpp:1216-1219, 1883-1921 call the matcher once per pair of a sequence): pair i at
+ * d_left / d_right + i * pair_stride_bytes, its map at d_disp + i * rows * cols.  Up to four pairs run side by side on streams
+ * of the context (a pair's launches are partly bound by the serial chains of its scan lines, and the others fill the
+ * gaps); everything is ordered after the work already on the context's stream and before what is enqueued on it next.
+ * Every map equals mdisp_stereosgbm_dev's.  d_workspace: mdisp_stereosgbm_batch_workspace_bytes(), or NULL (the context's). */
+size_t mdisp_stereosgbm_batch_workspace_bytes(int rows, int cols, int channels, const mdisp_stereosgbm_params* p, int n_pairs);
+int mdisp_stereosgbm_batch_dev(mdisp_ctx*, const uint8_t* d_left, const uint8_t* d_right, int n_pairs, size_t pair_stride_bytes,
+                               int rows, int cols, int channels, size_t pitch, const mdisp_stereosgbm_params* p,
+                               int16_t* d_disp, void* d_workspace, size_t workspace_bytes);
+
 /* cv::StereoBM::compute (see mdisp_stereobm_compute) on device-resident CV_8UC1 images; d_disp: device int16 HxW;
  * d_workspace: at least mdisp_stereobm_workspace_bytes() of device memory, or NULL to use the context's own. */
 size_t mdisp_stereobm_workspace_bytes(int rows, int cols, const mdisp_stereobm_params* p);
@@ -534,7 +544,7 @@ enum {
     MDISP_TUNE_SGM_FORCE_PREPASS = 3,  /* 1: upright strips + diagonal pre-pass even when byte path states fit      */
     MDISP_TUNE_SGM_LANES16 = 4,        /* 1: sixteen lanes per pixel whatever the disparity count                   */
     MDISP_TUNE_SGM_PER_DIRECTION = 5,  /* 1: one kernel per path direction (the fallback of unsupported shapes)     */
-    MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other  */
+    MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other (what large problems do); 2: the same with the selection as a kernel of its own instead of inside the last direction */
     MDISP_TUNE_SGM_PIPELINE = 7,       /* batches: 0 = row bands with four paths per sweep (default), 1 = sheared strips with a separate horizontal scan */
     MDISP_TUNE_SGM_PLANT_ERROR = 8,    /* 1: the next pipelined SGM call finds its hand-off error word already set  */
     MDISP_TUNE_SGM_BAND_SLACK = 9,     /* row bands: pixels a band stays behind its predecessor beyond the minimum  */
@@ -544,7 +554,8 @@ enum {
     MDISP_TUNE_SGM_ONE_LAUNCH = 13,    /* row bands: 0 = the two sweep directions as two launches per phase, 1 = both directions and both roles in one launch; default: one launch up to 96 pairs */
     MDISP_TUNE_SAT_INT_TABLES = 14,    /* 1: mdisp_sad_inte and the stereomatch_1 _inteOpti matchers sum in exact integer tables instead of the reference's CV_32F ones */
     MDISP_TUNE_SGM_RING_HANDOFF = 15,  /* row bands, one-launch schedule: 0 = one workgroup barrier per step (default), 1 = barrier-free waves with LDS rings between them (measured slower) */
-    MDISP_TUNE_COUNT = 16
+    MDISP_TUNE_SGBM_BATCH_LANES = 16,  /* mdisp_stereosgbm_batch_dev: pairs that run side by side (1..4; default 4) */
+    MDISP_TUNE_COUNT = 17
 };
 int mdisp_tuning_set(int key, int value);
 int mdisp_tuning_get(int key);

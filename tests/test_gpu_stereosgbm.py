@@ -46,12 +46,16 @@ CASES = [
 
 # small problems run the four directions of a group in one launch; large ones one direction per launch with the
 # running group sum kept in memory -- the tuning switch selects the second schedule at test sizes
-@pytest.fixture(params=["one launch per group", "one launch per direction"])
+# -- the tuning switch selects the second schedule at test sizes, with the selection inside the last direction (as large
+# problems run it) or as a kernel of its own
+@pytest.fixture(params=["one launch per group", "one launch per direction", "one launch per direction, separate selection"])
 def bt_schedule(request):
     from cameracalibration_amd import _lib
     _lib.tuning_reset()
     if request.param == "one launch per direction":
         _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 1)
+    elif request.param != "one launch per group":
+        _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 2)
     yield request.param
     _lib.tuning_reset()
 
@@ -84,6 +88,54 @@ def test_stereosgbm_full_size_frame_bit_exact(api, orc, mode):
     assert np.array_equal(raw, eraw)
     assert np.array_equal(got, exp)
     assert (got[:, D:] >= 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("shape", [(48, 150, 1, (0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, 0), 7, 0),
+                                   (37, 140, 3, (2, 32, 5, 8 * 3 * 25, 32 * 3 * 25, 2, 31, 15, 50, 2, 1), 5, 2),
+                                   (270, 960, 1, (0, 128, 7, 490, 1960, 1, 63, 10, 100, 32, 0), 6, 0),
+                                   (20, 50, 1, (0, 64, 5), 3, 1)])
+def test_stereosgbm_batch_equals_the_single_pair_call(api, orc, shape):
+    """mdisp_stereosgbm_batch_dev: pairs side by side on the context's streams, every map equal to the single-pair entry point's
+    (and the first one to the oracle), with work enqueued before and after the call on the context's stream; lanes = 0: default."""
+    import ctypes as C
+    import torch
+    from cameracalibration_amd import _lib
+    H, W, cn, args, n, lanes = shape
+    lib = _lib.load()
+    _lib.tuning_reset()
+    if lanes:
+        _lib.tuning_set(_lib.TUNE_SGBM_BATCH_LANES, lanes)
+    try:
+        p = api.StereoSGBM_create(*args)
+        pairs = [_pair(api, 0x5EED0200 + 3 * i, H, W, max(args[1] // 2, 8), cn) for i in range(n)]
+        dl = torch.from_numpy(np.stack([a for a, _ in pairs])).cuda()
+        dr = torch.from_numpy(np.stack([b for _, b in pairs])).cuda()
+        out = torch.full((n, H, W), 12345, dtype=torch.int16, device="cuda")
+        single = torch.empty((H, W), dtype=torch.int16, device="cuda")
+        ctx = _lib.Context(device=0)
+        nb = lib.mdisp_stereosgbm_batch_workspace_bytes(H, W, cn, C.byref(p), n)
+        assert nb >= lib.mdisp_stereosgbm_workspace_bytes(H, W, cn, C.byref(p))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for use_ws in (True, False):
+            out.fill_(12345)
+            torch.cuda.synchronize()
+            _lib.check(lib.mdisp_stereosgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), n, H * W * cn, H, W, cn, W * cn, C.byref(p),
+                                                      out.data_ptr(), ws.data_ptr() if use_ws else None, nb if use_ws else 0))
+            # enqueued right behind the batch on the context's stream: must see the lanes' results of the last pair
+            _lib.check(lib.mdisp_stereosgbm_dev(ctx.handle, dl[n - 1].data_ptr(), dr[n - 1].data_ptr(), H, W, cn, W * cn, C.byref(p),
+                                                single.data_ptr(), None, 0))
+            ctx.synchronize()
+            got = out.cpu().numpy()
+            assert np.array_equal(got[n - 1], single.cpu().numpy())
+            for i, (a, b) in enumerate(pairs):
+                assert np.array_equal(got[i], api.stereosgbm_compute(a, b, p)), "pair %d" % i
+            assert np.array_equal(got[0], orc.sgbm_bt(pairs[0][0], pairs[0][1], *args))
+        with pytest.raises(_lib.MdispError):
+            _lib.check(lib.mdisp_stereosgbm_batch_dev(ctx.handle, dl.data_ptr(), dr.data_ptr(), n, H * W * cn, H, W, cn, W * cn, C.byref(p),
+                                                      out.data_ptr(), ws.data_ptr(), 16))
+    finally:
+        _lib.tuning_reset()
 
 
 def test_stereosgbm_rejects_a_uniqueness_ratio_beyond_16_bits(api):
