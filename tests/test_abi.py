@@ -67,3 +67,29 @@ def test_rectify_maps_and_synth_are_host_only():
     left, right, gt = api.synth_pair(0x5EED0001, 48, 64, 16)
     assert left.shape == right.shape == gt.shape == (48, 64)
     assert right.max() == 255 and right.min() == 0 and gt.max() <= 15
+
+
+def test_no_wide_buffer_store_is_followed_by_an_overwrite_of_its_data():
+    """A 16-byte buffer store with its scalar offset in a register needs a wait state before a vector instruction that
+    overwrites its data registers, and the compiler does not leave one for that form (scripts/check_store_hazard.py):
+    the device code of the built library must not contain such a pair."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "cameracalibration_amd", "lib", "libmdisp.so")
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(root, "scripts", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
+        import pytest
+        pytest.skip("no llvm-objdump")
+    # the pattern itself, on a listing of the faulty form
+    import re
+    assert mod.regs("v[14:17]") == {14, 15, 16, 17} and mod.regs("v14") == {14}
+    import sys
+    argv = sys.argv
+    try:
+        sys.argv = ["check_store_hazard.py", lib]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
