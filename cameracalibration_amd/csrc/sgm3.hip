@@ -157,6 +157,9 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
             const bool mine = wants(i);
             if (!__any(mine)) return;
             const int need = min(i + 2 + ra.slack, W);    // pixels the band above must have published (two, plus the slack that decouples the bands)
+#ifdef SGM3_KNOCK_NO_BAND_WAIT      // timing experiment only (results wrong): bands never wait for the band above
+            seen = W;
+#endif
             if (seen < need) {
                 unsigned long long t0 = 0;
 #ifdef SGM3_TRACE
@@ -236,7 +239,12 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
             if (t + 1 < T) park(t + 1, w);
             if (t + 2 < T) request(t + 2, w);
             if (hasPrev) sample = __hip_atomic_load(progNb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(SGM3_KNOCK_NO_BARRIERS)
+#elif defined(SGM3_KNOCK_HALF_BARRIERS)
+            if ((t & 1) == 0) __syncthreads();
+#else
             __syncthreads();
+#endif
         }
         send(T - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,7 +471,12 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
         }
         if constexpr (!HONLY) {
             lds_get(above + SW, D);
+#if defined(SGM3_KNOCK_NO_BARRIERS)    // timing experiments only (results wrong): no step barrier / one per two steps
+#elif defined(SGM3_KNOCK_HALF_BARRIERS)
+            if (PAR == 0) __syncthreads();
+#else
             __syncthreads();   // st[t & 1] complete before the next step reads it
+#endif
         }
     };
     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
