@@ -21,7 +21,7 @@ E_BADARG, E_NODEVICE, E_HIP, E_UNSUPPORTED, E_RANGE, E_NOMEM = -1, -2, -3, -4, -
 (TUNE_SGM_SPLIT_MAX, TUNE_SGM_PATH_WAVES_MAX, TUNE_SGM_STRIP_LANES, TUNE_SGM_FORCE_PREPASS, TUNE_SGM_LANES16,
  TUNE_SGM_PER_DIRECTION, TUNE_SGBM_BT_SEQUENTIAL, TUNE_SGM_PIPELINE, TUNE_SGM_PLANT_ERROR, TUNE_SGM_BAND_SLACK, TUNE_SGM_PAIR_GROUP,
  TUNE_SGM_HAND_RING, TUNE_SGM_MEET_MAX, TUNE_SGM_ONE_LAUNCH, TUNE_SAT_INT_TABLES, TUNE_SGM_RING_HANDOFF, TUNE_SGBM_BATCH_LANES,
- TUNE_COUNT) = range(18)
+ TUNE_GIF_MC_TILES, TUNE_COUNT) = range(19)
 
 
 class mdisp_image(C.Structure):

@@ -13,6 +13,7 @@
 // applies them; slices run side by side in the grid's z.  Every Mat expression of the reference rounds to float per
 // operation; so does every operation here (no contraction).
 #include "common.h"
+#include "box_march.h"
 #include <float.h>
 
 namespace {
@@ -271,24 +272,129 @@ __global__ __launch_bounds__(256) void mc_pad_reflect_kernel(const u8* __restric
     for (int c = 0; c < cn; c++) dst[(size_t)y * dp + (size_t)x * cn + c] = src[(size_t)y * sp + (size_t)sx * cn + c];
 }
 
+// ---- the same filter on the marching box kernels (box_march.h): every input row is read once and the window sums are
+// running sums, so a box filter costs a few operations per pixel whatever the window; the price is that the quantities
+// of a slice go through memory between passes (two box filters per pass).  Per slice and guide channel c: a pass over
+// (G_c, G_c^2) leaves mean and variance, a pass over (P, G_c P) leaves a_c and adds a_c mean(G_c) to the running dot product
+// (the last channel's pass writes b = mean(P) - dot); then the planes of a two at a time, and b, are box-filtered and
+// accumulated into the output in the reference's order.  Same float operations per pixel as the tile kernels.
+__device__ __forceinline__ int mc_guide_raw(const McGuide& g, int c, int x, int y, int k)
+{
+    return c < g.acn ? g.a[(size_t)y * g.ap + (size_t)(x + g.aOff0 + k * g.aOffStep) * g.acn + c]
+                     : g.b[(size_t)y * g.bp + (size_t)(x + g.bOff0 + k * g.bOffStep) * g.bcn + (c - g.acn)];
+}
+__device__ __forceinline__ float mc_norm(int v, const float2& co) { return __fadd_rn(__fmul_rn((float)v, co.x), co.y); }
+
+struct McLoadGG {
+    McGuide g; int c, k0; const float2* gco; float2 gc;
+    struct Raw { int v; };
+    __device__ void begin(int k) { gc = gco[k]; }
+    __device__ Raw fetch(int x, int y, int k) const { Raw r; r.v = mc_guide_raw(g, c, x, y, k0 + k); return r; }
+    __device__ void finish(const Raw& r, float& q0, float& q1) const { q0 = mc_norm(r.v, gc); q1 = __fmul_rn(q0, q0); }
+};
+struct McStoreMV {
+    float* MG; float* VAR; size_t N; int W; double scale;
+    __device__ void operator()(int x, int y, int k, double s0, double s1) const
+    {
+        const size_t o = (size_t)k * N + (size_t)y * W + x;
+        const float mg = (float)(s0 * scale), cgg = (float)(s1 * scale);
+        MG[o] = mg; VAR[o] = __fsub_rn(cgg, __fmul_rn(mg, mg));
+    }
+};
+struct McLoadPGP {
+    McGuide g; int c, k0; const float* P; size_t N; int W; const float2* gco; const float2* pco; float2 gc, pc;
+    struct Raw { float p; int v; };
+    __device__ void begin(int k) { gc = gco[k]; pc = pco[k]; }
+    __device__ Raw fetch(int x, int y, int k) const { Raw r; r.p = P[(size_t)k * N + (size_t)y * W + x]; r.v = mc_guide_raw(g, c, x, y, k0 + k); return r; }
+    __device__ void finish(const Raw& r, float& q0, float& q1) const
+    {
+        q0 = __fadd_rn(__fmul_rn(r.p, pc.x), pc.y);
+        q1 = __fmul_rn(mc_norm(r.v, gc), q0);
+    }
+};
+struct McStoreA {
+    float* A; float* DOT; float* B; const float* MG; const float* VAR; size_t N; int W, cn, c, variant; float epsf; double scale;
+    __device__ void operator()(int x, int y, int k, double s0, double s1) const
+    {
+        const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
+        const float mp = (float)(s0 * scale), cgp = (float)(s1 * scale), mg = MG[o], var = VAR[o];
+        const float cov = __fsub_rn(cgp, __fmul_rn(mg, mp));
+        float den;
+        if (variant == 0) den = __fadd_rn(var, epsf);
+        else den = __fadd_rn(var, var != 0.f ? __fdiv_rn(__fmul_rn(var, epsf), var) : 0.f);
+        const float av = den != 0.f ? __fdiv_rn(cov, den) : 0.f;
+        A[((size_t)k * cn + c) * N + i] = av;
+        const float dot = __fadd_rn(c == 0 ? 0.f : DOT[o], __fmul_rn(av, mg));
+        if (c == cn - 1) B[o] = __fsub_rn(mp, dot);
+        else DOT[o] = dot;
+    }
+};
+// two planes [k][plane][N] (or one: second = nullptr)
+struct McLoadPlanes {
+    const float* P0; const float* P1; size_t kstride, N; int W;
+    struct Raw { float a, b; };
+    __device__ void begin(int) {}
+    __device__ Raw fetch(int x, int y, int k) const
+    {
+        const size_t o = (size_t)k * kstride + (size_t)y * W + x;
+        Raw r; r.a = P0[o]; r.b = P1 ? P1[o] : 0.f;
+        return r;
+    }
+    __device__ void finish(const Raw& r, float& q0, float& q1) const { q0 = r.a; q1 = r.b; }
+};
+// V (+)= mean(a_c) G_c (+ mean(a_c+1) G_c+1), or V += mean(b)
+struct McStoreDot {
+    McGuide g; int k0, c, nq; const float2* gco; float* V; size_t N; int W; double scale; bool isB;
+    __device__ void operator()(int x, int y, int k, double s0, double s1) const
+    {
+        const size_t o = (size_t)k * N + (size_t)y * W + x;
+        const float m0 = (float)(s0 * scale), m1 = (float)(s1 * scale);
+        if (isB) { V[o] = __fadd_rn(V[o], m0); return; }
+        const float2 gc = gco[k];
+        float acc = c == 0 ? 0.f : V[o];
+        acc = __fadd_rn(acc, __fmul_rn(m0, mc_norm(mc_guide_raw(g, c, x, y, k0 + k), gc)));
+        if (nq == 2) acc = __fadd_rn(acc, __fmul_rn(m1, mc_norm(mc_guide_raw(g, c + 1, x, y, k0 + k), gc)));
+        V[o] = acc;
+    }
+};
+// getCostSAD_d slices: (|ref - oth|, nothing) -> mean
+struct McLoadCost {
+    McCost c; int k0;
+    struct Raw { int a, b; };
+    __device__ void begin(int) {}
+    __device__ Raw fetch(int x, int y, int k) const
+    {
+        Raw r; r.a = c.ref[(size_t)y * c.rp + x]; r.b = c.oth[(size_t)y * c.op + x + c.off0 + (k0 + k) * c.offStep];
+        return r;
+    }
+    __device__ void finish(const Raw& r, float& q0, float& q1) const { q0 = (float)(r.a > r.b ? r.a - r.b : r.b - r.a); q1 = 0.f; }
+};
+struct McStoreMean {
+    float* out; size_t N; int W; double scale;
+    __device__ void operator()(int x, int y, int k, double s0, double) const { out[(size_t)k * N + (size_t)y * W + x] = (float)(s0 * scale); }
+};
+
 size_t mc_lds_bytes(int r) { return (size_t)(MC_TH + r - 1) * MC_TW * sizeof(double) + (size_t)(MC_TH + r - 1) * (MC_TW + r - 1) * sizeof(float); }
 
 }  // namespace
 
 // ---- host drivers ---------------------------------------------------------------------------------------------------
 
+// the tile kernels (kept behind MDISP_TUNE_GIF_MC_TILES: the tests run both) hold a tile and its halo in LDS
+static bool mc_use_tiles() { return md_tune(MDISP_TUNE_GIF_MC_TILES) > 0; }
 int md_mc_check_window(int r)
 {
     MD_REQUIRE(r > 0, MDISP_E_BADARG, "window must be positive");
-    MD_REQUIRE(mc_lds_bytes(r) <= 64 * 1024, MDISP_E_UNSUPPORTED, "window %d needs more than 64 KB of LDS per tile (at most 47)", r);
+    if (mc_use_tiles()) MD_REQUIRE(mc_lds_bytes(r) <= 64 * 1024, MDISP_E_UNSUPPORTED, "window %d needs more than 64 KB of LDS per tile (at most 47)", r);
+    else MD_REQUIRE(march_supported(r), MDISP_E_UNSUPPORTED, "window %d is wider than the %d columns a marching workgroup holds", r, MW);
     return MDISP_OK;
 }
 
 // slices per batch and scratch bytes of md_mc_filter_wta
 static int mc_batch(int H, int W, int cn, int n)
 {
-    const size_t per = (size_t)H * W * 4 * (cn + 3);      // raw slice, a planes, b, filtered
-    size_t nb = ((size_t)1 << 30) / per;
+    const size_t per = (size_t)H * W * 4 * (cn + 6);      // raw slice, a planes, b, filtered; mean, variance, running dot product
+    size_t nb = ((size_t)8 << 30) / per;      // a marching launch needs hundreds of slices x strips to fill the device: up to 8 GB of planes
     if (nb < 1) nb = 1;
     if (nb > (size_t)n) nb = n;
     return (int)nb;
@@ -297,7 +403,7 @@ size_t md_mc_scratch_bytes(int H, int W, int cn, int n, int Wa, int Wb)
 {
     const int nb = mc_batch(H, W, cn, n);
     const size_t N = (size_t)H * W;
-    return md_align(N * 4 * nb, 256) * 3 + md_align(N * 4 * nb * cn, 256) + md_align(N * 4, 256) +
+    return md_align(N * 4 * nb, 256) * 6 + md_align(N * 4 * nb * cn, 256) + md_align(N * 4, 256) +
            md_align((size_t)nb * 8, 256) * 3 + md_align(Wa, 256) * 2 + md_align(Wb > 0 ? Wb : 1, 256) * 2 + 4096;
 }
 
@@ -325,6 +431,9 @@ int md_mc_filter_wta(hipStream_t s, const McGuideHost& gh, int H, int W, int r, 
     float* V = (float*)take(N * 4 * nb);
     float* A = (float*)take(N * 4 * nb * cn);
     float* best = (float*)take(N * 4);
+    float* MG = (float*)take(N * 4 * nb);
+    float* VAR = (float*)take(N * 4 * nb);
+    float* DOT = (float*)take(N * 4 * nb);
     u32* pmm = (u32*)take((size_t)nb * 8);
     float2* gco = (float2*)take((size_t)nb * 8);
     float2* pco = (float2*)take((size_t)nb * 8);
@@ -337,26 +446,54 @@ int md_mc_filter_wta(hipStream_t s, const McGuideHost& gh, int H, int W, int r, 
     if (gh.bcn) mc_col_minmax_kernel<<<(gh.bW + 255) / 256, 256, 0, s>>>(gh.b, gh.bp, H, gh.bW, gh.bcn, bMin, bMax);
     const dim3 tiles((W + MC_TW - 1) / MC_TW, (H + MC_TH - 1) / MC_TH);
     const size_t lds = mc_lds_bytes(r);
+    const bool useTiles = mc_use_tiles();
+    const double scale = 1.0 / ((double)r * r);
     for (int k0 = 0; k0 < n; k0 += nb) {
         const int m = n - k0 < nb ? n - k0 : nb;
         const dim3 grid(tiles.x, tiles.y, m);
         const float* P = Praw;
-        if (cost) mc_sad_cost_kernel<<<grid, 256, mc_lds_bytes(costWin), s>>>(*cost, H, W, costWin, k0, Praw);
+        if (cost && useTiles) mc_sad_cost_kernel<<<grid, 256, mc_lds_bytes(costWin), s>>>(*cost, H, W, costWin, k0, Praw);
+        else if (cost) {
+            McLoadCost lc{*cost, k0};
+            McStoreMean sm{Praw, N, W, 1.0 / ((double)costWin * costWin)};
+            MD_TRY(dual_box_march(s, m, H, W, costWin, 0, 0, H, lc, sm));
+        }
         else P = dSlices + (size_t)k0 * N;
         mc_mm_init_kernel<<<(m + 63) / 64, 64, 0, s>>>(pmm, m);
         int mb = (int)((N + 256 * 8 - 1) / (256 * 8));
         if (mb > 512) mb = 512;
         mc_minmax_kernel<<<dim3(mb, m), 256, 0, s>>>(P, N, pmm);
         mc_coeff_kernel<<<m, 256, 0, s>>>(g, W, k0, aMin, aMax, bMin, bMax, pmm, gco, pco);
-        McAbArgs ab{};
-        ab.g = g; ab.H = H; ab.W = W; ab.r = r; ab.k0 = k0; ab.variant = variant; ab.epsf = (float)eps;
-        ab.P = P; ab.gco = gco; ab.pco = pco; ab.A = A; ab.B = Bp;
-        mc_ab_kernel<<<grid, 256, lds, s>>>(ab);
-        McOutArgs oa{};
-        oa.g = g; oa.H = H; oa.W = W; oa.r = r; oa.k0 = k0; oa.gco = gco; oa.A = A; oa.B = Bp;
-        oa.V = dFiltered ? dFiltered + (size_t)k0 * N : V;
-        mc_out_kernel<<<grid, 256, lds, s>>>(oa);
-        if (dDisp) mc_wta_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(oa.V, N, m, k0 == 0, d0 + k0, best, dDisp);
+        float* const Vout = dFiltered ? dFiltered + (size_t)k0 * N : V;
+        if (useTiles) {
+            McAbArgs ab{};
+            ab.g = g; ab.H = H; ab.W = W; ab.r = r; ab.k0 = k0; ab.variant = variant; ab.epsf = (float)eps;
+            ab.P = P; ab.gco = gco; ab.pco = pco; ab.A = A; ab.B = Bp;
+            mc_ab_kernel<<<grid, 256, lds, s>>>(ab);
+            McOutArgs oa{};
+            oa.g = g; oa.H = H; oa.W = W; oa.r = r; oa.k0 = k0; oa.gco = gco; oa.A = A; oa.B = Bp;
+            oa.V = Vout;
+            mc_out_kernel<<<grid, 256, lds, s>>>(oa);
+        } else {
+            for (int c = 0; c < cn; c++) {
+                McLoadGG lgg{g, c, k0, gco, {}};
+                McStoreMV smv{MG, VAR, N, W, scale};
+                MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, lgg, smv));
+                McLoadPGP lp{g, c, k0, P, N, W, gco, pco, {}, {}};
+                McStoreA sa{A, DOT, Bp, MG, VAR, N, W, cn, c, variant, (float)eps, scale};
+                MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, lp, sa));
+            }
+            for (int c = 0; c < cn; c += 2) {
+                const int nq = c + 1 < cn ? 2 : 1;
+                McLoadPlanes la{A + (size_t)c * N, nq == 2 ? A + (size_t)(c + 1) * N : nullptr, (size_t)cn * N, N, W};
+                McStoreDot sd{g, k0, c, nq, gco, Vout, N, W, scale, false};
+                MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, la, sd));
+            }
+            McLoadPlanes lb{Bp, nullptr, N, N, W};
+            McStoreDot sb{g, k0, 0, 1, gco, Vout, N, W, scale, true};
+            MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, lb, sb));
+        }
+        if (dDisp) mc_wta_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(Vout, N, m, k0 == 0, d0 + k0, best, dDisp);
     }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
@@ -410,7 +547,12 @@ int md_cost_sad_d(hipStream_t s, const u8* ref, size_t rp, const u8* oth, size_t
     MD_TRY(md_mc_check_window(win));
     McCost c{};
     c.ref = ref; c.rp = rp; c.oth = oth; c.op = op; c.off0 = off; c.offStep = 0;
-    mc_sad_cost_kernel<<<dim3((W + MC_TW - 1) / MC_TW, (H + MC_TH - 1) / MC_TH, 1), 256, mc_lds_bytes(win), s>>>(c, H, W, win, 0, out);
+    if (mc_use_tiles()) mc_sad_cost_kernel<<<dim3((W + MC_TW - 1) / MC_TW, (H + MC_TH - 1) / MC_TH, 1), 256, mc_lds_bytes(win), s>>>(c, H, W, win, 0, out);
+    else {
+        McLoadCost lc{c, 0};
+        McStoreMean sm{out, (size_t)H * W, W, 1.0 / ((double)win * win)};
+        MD_TRY(dual_box_march(s, 1, H, W, win, 0, 0, H, lc, sm));
+    }
     MD_HIP(hipGetLastError());
     return MDISP_OK;
 }

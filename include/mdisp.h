@@ -555,7 +555,8 @@ enum {
     MDISP_TUNE_SAT_INT_TABLES = 14,    /* 1: mdisp_sad_inte and the stereomatch_1 _inteOpti matchers sum in exact integer tables instead of the reference's CV_32F ones */
     MDISP_TUNE_SGM_RING_HANDOFF = 15,  /* row bands, one-launch schedule: 0 = one workgroup barrier per step (default), 1 = barrier-free waves with LDS rings between them (measured slower) */
     MDISP_TUNE_SGBM_BATCH_LANES = 16,  /* mdisp_stereosgbm_batch_dev: pairs that run side by side (1..4; default 4) */
-    MDISP_TUNE_COUNT = 17
+    MDISP_TUNE_GIF_MC_TILES = 17,      /* guided filter with a multi-channel guide: 1 = the LDS-tile kernels (windows up to 47) instead of the marching ones */
+    MDISP_TUNE_COUNT = 18
 };
 int mdisp_tuning_set(int key, int value);
 int mdisp_tuning_get(int key);

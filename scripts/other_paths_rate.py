@@ -116,3 +116,25 @@ guide = api.synth_pair(0x5EED0001, H, W, 64)[0]
 dmap = (rng.random((H, W)) * 64).astype(np.float32)
 dt, _ = host_rate(lambda: api.fastGlobalSmootherFilter(guide, dmap, 8000.0, 0.5), H, W, 1, n=5)
 print(f"fastGlobalSmootherFilter (lambda 8000, sigma 0.5, 3 iterations) {W}x{H} host API: {dt*1e3:.2f} ms")
+
+# the guided-filter matchers of stereomatch_1 at the reference's own parameters (methods/method_StereoMatching.h:179-187:
+# winSize 35, minDisparity 186, numDisparity 144) on a 1280x720 colour pair, computeSimilarity, and the float-table SAD
+H, W, D = 720, 1280, 144
+Lg, Rg, _ = api.synth_pair(0x5EED0001, H, W, 256)
+rng = np.random.default_rng(7)
+gain = rng.integers(200, 256, 3)
+Lc = np.stack([(Lg.astype(np.int32) * g // 255).astype(np.uint8) for g in gain], axis=-1)
+Rc = np.stack([(Rg.astype(np.int32) * g // 255).astype(np.uint8) for g in gain], axis=-1)
+sm = api.stereomatch_1
+for name, fn in (("computeAdaptiveWeight_GuidedF", lambda: sm.computeAdaptiveWeight_GuidedF(Lc, Rc)),
+                 ("computeAdaptiveWeight_GuidedF_2", lambda: sm.computeAdaptiveWeight_GuidedF_2(Lc, Rc)),
+                 ("computeAdaptiveWeight_GuidedF_3", lambda: sm.computeAdaptiveWeight_GuidedF_3(Lc, Rc))):
+    dt, r = host_rate(fn, H, W, D, n=2)
+    print(f"{name} (win 35, minD 186, 144 candidates) {W}x{H} colour, host API: {dt*1e3:.1f} ms  {r:.0f} Mdisp/s")
+costs = []
+dt, r = host_rate(lambda: sm.computeSimilarity(Lc, Rc, costs, 0.1, 7.0, 2.0, api.DISPARITY_LEFT, None, 0, 30), H, W, 30, n=2)
+print(f"computeSimilarity (30 candidates) {W}x{H} colour, host API (30 float slices copied out): {dt*1e3:.1f} ms  {r:.0f} Mdisp/s")
+p = api.StereoMatchParam(imgLeft=Lg, imgRight=Rg, winSize=7, minDisparity=0, maxDisparity=255, isDispLeft=True)
+for name, mode in (("float tables (the reference's CV_32F integral)", api.SAT_F32), ("integer tables", api.SAT_INT)):
+    dt, r = host_rate(lambda: api.computeSAD_inteOpti(p, None, mode), H, W, 256)
+    print(f"computeSAD_inteOpti, {name}, win 7 {W}x{H} D=256 host API: {dt*1e3:.2f} ms  {r:.0f} Mdisp/s")

@@ -8,6 +8,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["marching box kernels", "LDS-tile box kernels"])
+def mc_kernels(request):
+    """Every test runs on both implementations of the box filters (the marching kernels are what the library uses)."""
+    from cameracalibration_amd import _lib
+    _lib.tuning_reset()
+    if request.param == "LDS-tile box kernels":
+        _lib.tuning_set(_lib.TUNE_GIF_MC_TILES, 1)
+    yield request.param
+    _lib.tuning_reset()
+
+
 def _colour_pair(seed, H, W, shift):
     rng = np.random.default_rng(seed)
     base = rng.integers(0, 256, size=(H, W + 2 * shift + 8, 3)).astype(np.int32)
