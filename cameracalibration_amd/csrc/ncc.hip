@@ -60,12 +60,27 @@ __device__ __forceinline__ double ncc_value(const NccView& L, int xl, const NccV
     const int h = win / 2;
     const float ml = L.mean[(size_t)y * L.W + xl], mr = R.mean[(size_t)y * R.W + xr];
     double c = 0.0;
-    for (int j = 0; j < win; j++) {
-        const u8* rl = L.img + (size_t)refl(y + j - h, L.H) * L.pitch;
-        const u8* rr = R.img + (size_t)refl(y + j - h, R.H) * R.pitch;
-        for (int i = 0; i < win; i++) {
-            const float a = __fsub_rn((float)rl[refl(xl + i - h, L.W)], ml), b = __fsub_rn((float)rr[refl(xr + i - h, R.W)], mr);
-            c += (double)__fmul_rn(a, b);
+    // away from the image border (for every lane of the wave) no index is reflected: same taps in the same order, without
+    // the index arithmetic per tap
+    const bool inner = xl - h >= 0 && xl + h < L.W && xr - h >= 0 && xr + h < R.W && y - h >= 0 && y + h < L.H && y + h < R.H;
+    if (__all(inner)) {
+        const u8* rl = L.img + (size_t)(y - h) * L.pitch + (xl - h);
+        const u8* rr = R.img + (size_t)(y - h) * R.pitch + (xr - h);
+        for (int j = 0; j < win; j++, rl += L.pitch, rr += R.pitch) {
+#pragma unroll 5
+            for (int i = 0; i < win; i++) {
+                const float a = __fsub_rn((float)rl[i], ml), b = __fsub_rn((float)rr[i], mr);
+                c += (double)__fmul_rn(a, b);
+            }
+        }
+    } else {
+        for (int j = 0; j < win; j++) {
+            const u8* rl = L.img + (size_t)refl(y + j - h, L.H) * L.pitch;
+            const u8* rr = R.img + (size_t)refl(y + j - h, R.H) * R.pitch;
+            for (int i = 0; i < win; i++) {
+                const float a = __fsub_rn((float)rl[refl(xl + i - h, L.W)], ml), b = __fsub_rn((float)rr[refl(xr + i - h, R.W)], mr);
+                c += (double)__fmul_rn(a, b);
+            }
         }
     }
     return c / (L.energy[(size_t)y * L.W + xl] * R.energy[(size_t)y * R.W + xr]);
