@@ -346,8 +346,13 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
     const int lane = threadIdx.x & 63;
     // the line is the same for every lane of a wave: kept in a scalar register, so that the loop bounds are uniform
     int line = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (line >= (OPP && FIRST ? 2 * nlines : nlines)) return;
-    if (OPP && FIRST && line >= nlines) { line -= nlines; dx = -dx; dy = -dy; accp = static_cast<AccT*>(a.opp); }
+    // OPP without LAST: the opposite direction runs beside the launch's own, on as many more waves; it is always the first
+    // to write its buffer, whether the launch's own direction is the group's first or not
+    constexpr bool BESIDE = OPP && !LAST;
+    if (line >= (BESIDE ? 2 * nlines : nlines)) return;
+    const bool oppHalf = BESIDE && line >= nlines;         // (wave-uniform: `line` lives in a scalar register)
+    if (oppHalf) { line -= nlines; dx = -dx; dy = -dy; accp = static_cast<AccT*>(a.opp); }
+    const bool first = FIRST || oppHalf;
     if (MULTI) {
         int i = 0;
         while (i < 3 && line >= a.mfirst[i + 1]) i++;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         const int tf = min(t, n - 1);
         const size_t o = ((size_t)(y0 + tf * dy) * W + (x0 + tf * dx)) * D + kl;
         in.c = bt_ld(reinterpret_cast<const V*>(a.C + o));
-        if (!FIRST) in.old = bt_ld(reinterpret_cast<const AV*>(accInp + o));
+        if (!first) in.old = bt_ld(reinterpret_cast<const AV*>(accInp + o));
         if (LAST && !a.firstGroup) in.sOld = bt_ld(reinterpret_cast<const V*>(Sin + o));
         static_assert(!SEL || (LAST && !MULTI), "selection belongs to the direction that completes S");
         if (OPP && LAST) in.opp = bt_ld(reinterpret_cast<const AV*>(static_cast<const AccT*>(a.opp) + o));
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
         int16_t c[ND];
         int old[ND];
         __builtin_memcpy(c, &in.c, sizeof(V));
-        if (FIRST) {
+        if (first) {
 #pragma unroll
             for (int j = 0; j < ND; j++) old[j] = 0;
         } else {
@@ -481,9 +486,9 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
                 for (int j = 0; j < ND; j++) atomicAdd(ap + j, Ln[j]);
             } else if constexpr (PK) {
                 u32 aw[NP];
-                if (!FIRST) __builtin_memcpy(aw, &in.old, sizeof(AV));
+                if (!first) __builtin_memcpy(aw, &in.old, sizeof(AV));
 #pragma unroll
-                for (int i = 0; i < NP; i++) aw[i] = FIRST ? Lw[i] : pk_add_s16(aw[i], Lw[i]);
+                for (int i = 0; i < NP; i++) aw[i] = first ? Lw[i] : pk_add_s16(aw[i], Lw[i]);
                 AV packedAcc;
                 __builtin_memcpy(&packedAcc, aw, sizeof(AV));
                 bt_st(reinterpret_cast<AV*>(accp + o), packedAcc);
@@ -574,6 +579,112 @@ __global__ __launch_bounds__(256) void bt_path_kernel(PathArgs a, int dx, int dy
 #pragma unroll
     for (int u = 0; u < PF; u++)
         if (t + u < n) step(t + u, ring[u]);
+}
+
+// The vertical window sum and the downward path in one pass: a wave owns a column and walks down the image with the running
+// window sum of bt_vsum_kernel; the block cost of a pixel is complete the moment it is formed, so the wave runs the
+// recursion of the direction (0, +1) on it at once and leaves both the block cost (for the other directions) and the
+// group's first sum.  Saves that direction's launch: one read of the block cost and one of the group sum.
+template <int ND, class AccT>
+__global__ __launch_bounds__(256) void bt_vsum_down_kernel(const int16_t* __restrict__ in, BtGeom g, int16_t* __restrict__ out,
+                                                           AccT* __restrict__ acc, int P1, int P2)
+{
+    const int lane = threadIdx.x & 63;
+    const int x1 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (x1 >= g.W1) return;
+    const int D = g.D, H = g.H, h = g.bs / 2;
+    const int k0 = lane * ND;
+    const bool mine = k0 < D;
+    const size_t rowN = (size_t)g.W1 * D, col = (size_t)x1 * D + (mine ? k0 : 0);
+    const bool frozen = x1 == 0;                          // row 0's sum in every row (bt_vsum_kernel)
+    typedef typename CVec<ND>::type V;
+    typedef typename AccVec<AccT, ND>::type AV;
+    auto ld = [&](int y) { return bt_ld<4>(reinterpret_cast<const V*>(in + (size_t)y * rowN + col)); };
+    int s[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) s[j] = 0;
+    for (int i = -h; i <= h; i++) {
+        const V v = ld(min(max(i, 0), H - 1));
+        int16_t e[ND];
+        __builtin_memcpy(e, &v, sizeof(V));
+#pragma unroll
+        for (int j = 0; j < ND; j++) s[j] += (int)e[j];
+    }
+    int Lp[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) Lp[j] = mine ? 0 : 32767;
+    int minPrev = 0;
+    auto step = [&](int y) {
+        int16_t c[ND];
+#pragma unroll
+        for (int j = 0; j < ND; j++) c[j] = (int16_t)s[j];            // the 16-bit wrap of the stored block cost
+        const int left = wave_shr1(Lp[ND - 1], 32767), right = wave_shl1(Lp[0], 32767);
+        const int delta = minPrev + P2;
+        int Ln[ND], mn = BT_BIG;
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+            const int lo = j > 0 ? Lp[j - 1] : left, hi = j < ND - 1 ? Lp[j + 1] : right;
+            int L = (int)c[j] + min(min(Lp[j], lo + P1), min(hi + P1, delta)) - delta;
+            L = (int)(int16_t)L;
+            if (!mine) L = BT_BIG;
+            Ln[j] = L;
+            mn = min(mn, L);
+        }
+        mn = wave_min_dpp(mn);
+        if (mine) {
+            const size_t o = (size_t)y * rowN + col;
+            V pc;
+            __builtin_memcpy(&pc, c, sizeof(V));
+            bt_st<4>(reinterpret_cast<V*>(out + o), pc);
+            AccT av[ND];
+#pragma unroll
+            for (int j = 0; j < ND; j++) av[j] = (AccT)Ln[j];
+            if constexpr (sizeof(AV) <= 16) {
+                AV pa;
+                __builtin_memcpy(&pa, av, sizeof(AV));
+                bt_st(reinterpret_cast<AV*>(acc + o), pa);
+            } else {
+#pragma unroll
+                for (int j = 0; j < ND; j++) acc[o + j] = av[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ND; j++) Lp[j] = mine ? Ln[j] : 32767;
+        minPrev = mn;
+    };
+    // the rows entering and leaving the window of step y (y >= 1), requested PF steps ahead; requests beyond the last
+    // row repeat it (whole groups of steps without an exit, as in bt_path_kernel)
+    constexpr int PF = ND <= 2 ? 8 : 4;
+    struct In { V a, b; };
+    In ring[PF];
+    auto fetch = [&](int y, In& in) {
+        const int yy = min(y, H - 1);
+        in.a = ld(min(yy + h, H - 1));
+        in.b = ld(max(yy - h - 1, 0));
+    };
+    auto advance = [&](const In& in) {
+        int16_t ea[ND], eb[ND];
+        __builtin_memcpy(ea, &in.a, sizeof(V));
+        __builtin_memcpy(eb, &in.b, sizeof(V));
+#pragma unroll
+        for (int j = 0; j < ND; j++) s[j] += frozen ? 0 : (int)ea[j] - (int)eb[j];
+    };
+#pragma unroll
+    for (int u = 0; u < PF; u++) fetch(1 + u, ring[u]);
+    step(0);
+    int y = 1;
+    for (; y + PF <= H; y += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const In cur = ring[u];
+            fetch(y + u + PF, ring[u]);
+            advance(cur);
+            step(y + u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        if (y + u < H) { advance(ring[u]); step(y + u); }
 }
 
 // S = saturate_cast<short>(S + acc)   (first group: S starts at zero)
@@ -930,6 +1041,16 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
         return MDISP_OK;
     }
     MD_REQUIRE((size_t)W * 8 + 16 <= 64 * 1024, MDISP_E_RANGE, "image wider than 8190 columns");
+    const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
+    // a path value lies in [-P2, Cmax]; three of them fit int16 when the block cost cannot exceed 10922 (then it cannot
+    // have wrapped either): block cost <= bs^2 * cn * (2 * ftzero + 255 / 4)
+    const long cmax = (long)g.bs * g.bs * cn * (2 * g.ftzero + 63);
+    const bool acc16 = 3 * std::max<long>(cmax, P2) <= 32767;
+    const int seqTune = md_tune(MDISP_TUNE_SGBM_BT_SEQUENTIAL);
+    const bool largeSchedule = !(V <= BT_MULTI_MAX_UNITS && seqTune <= 0);      // one launch per direction
+    // large problems: the vertical window sum also runs the downward path (MDISP_TUNE_SGBM_BT_SEQUENTIAL = 3 keeps them apart)
+    const size_t rowLdsEarly = (size_t)2 * cn * ((BT_SEG + g.bs) + (BT_SEG + g.bs + 255)) * sizeof(u32) + (size_t)(g.bs + 1) * 256 * sizeof(int16_t);
+    const bool fuseDown = largeSchedule && seqTune != 3 && rowLdsEarly <= 60 * 1024;
     const dim3 gi((W + 255) / 256, H), gv(nblk((size_t)g.W1 * g.D), H);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dL, pitch, g, pl1);
     bt_planes_kernel<<<gi, 256, 0, s>>>(dR, pitch, g, pl2);
@@ -940,22 +1061,29 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
         if (cn == 1) bt_cost_hsum_kernel<1><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
         else if (cn == 3) bt_cost_hsum_kernel<3><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
         else bt_cost_hsum_kernel<0><<<gh, 256, rowLds, s>>>(pl1, pl2, g, v1);
-        bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D / 4), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
+        if (!fuseDown) bt_vsum_kernel<<<dim3(nblk((size_t)g.W1 * g.D / 4), (H + BT_VBAND - 1) / BT_VBAND), 256, 0, s>>>(v1, g, v0);      // v0 = block cost C
     } else {
         bt_cost_kernel<<<gv, 256, 0, s>>>(pl1, pl2, g, v0);
         bt_window_kernel<false><<<gv, 256, 0, s>>>(v0, g, v1);
         bt_window_kernel<true><<<gv, 256, 0, s>>>(v1, g, v0);
     }
     MD_HIP(hipGetLastError());
-    if (dCost) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
+    if (dCost && !fuseDown) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
     static const int DIRS[8][2] = {{+1, 0}, {+1, +1}, {0, +1}, {-1, +1}, {-1, 0}, {-1, -1}, {0, -1}, {+1, -1}};
     PathArgs pa{};
     pa.C = v0; pa.acc = acc; pa.accIn = acc; pa.opp = v1; pa.H = H; pa.W1 = g.W1; pa.D = g.D; pa.P1 = P1; pa.P2 = P2; pa.S = S; pa.firstGroup = 1;
-    const int nd = g.D <= 64 ? 1 : g.D <= 128 ? 2 : g.D <= 256 ? 4 : 8;
-    // a path value lies in [-P2, Cmax]; three of them fit int16 when the block cost cannot exceed 10922 (then it cannot
-    // have wrapped either): block cost <= bs^2 * cn * (2 * ftzero + 255 / 4)
-    const long cmax = (long)g.bs * g.bs * cn * (2 * g.ftzero + 63);
-    const bool acc16 = 3 * std::max<long>(cmax, P2) <= 32767;
+    if (fuseDown) {
+        const dim3 gf((g.W1 + 3) / 4);
+#define BT_FUSED(NDV)                                                                                          \
+        do {                                                                                                   \
+            if (acc16) bt_vsum_down_kernel<NDV, int16_t><<<gf, 256, 0, s>>>(v1, g, v0, (int16_t*)acc, P1, P2);   \
+            else bt_vsum_down_kernel<NDV, int><<<gf, 256, 0, s>>>(v1, g, v0, acc, P1, P2);                       \
+        } while (0)
+        if (nd == 1) BT_FUSED(1); else if (nd == 2) BT_FUSED(2); else if (nd == 4) BT_FUSED(4); else BT_FUSED(8);
+#undef BT_FUSED
+        MD_HIP(hipGetLastError());
+        if (dCost) MD_HIP(hipMemcpyAsync(dCost, v0, V * 2, hipMemcpyDeviceToDevice, s));
+    }
     const int uniq = p->uniquenessRatio >= 0 ? p->uniquenessRatio : 10;
     pa.key = selKey; pa.rec = selRec; pa.W = W; pa.minX1 = g.minX1; pa.minD = g.minD; pa.q = 100 - uniq;
     bool selected = false;        // the last direction has selected: records instead of S
@@ -1002,6 +1130,8 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             const int nlines = dy == 0 ? H : (dx == 0 ? g.W1 : g.W1 + H - 1);
             dim3 gp((nlines + 3) / 4);
             if (opp && grp == 1 && i == 0) continue;                     // <- ran beside ->
+            const bool fused0 = fuseDown && grp == 0;                    // the downward path ran with the vertical window sum: it was the group's first
+            if (fused0 && i == 2) continue;
             const bool oppFirst = opp && grp == 0 && i == 0;
             const bool oppLast = opp && grp == 0 && i == ndir - 1 && p->mode == MDISP_SGBM_MODE_SGBM;      // MODE_SGBM: <- is all of the second group
             pa.accIn = (opp && grp == 1 && i == 1) ? (const void*)v1 : (const void*)acc;
@@ -1011,12 +1141,13 @@ int md_stereosgbm_run(hipStream_t s, const u8* dL, const u8* dR, size_t pitch, i
             if (sel) { MD_HIP(hipMemsetAsync(selKey, 0xFF, N * 4, s)); selected = true; }
 #define BT_PATH(NDV, ACC, PKV)                                                                                 \
             do {                                                                                               \
-                if (oppFirst) bt_path_kernel<NDV, true, false, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);          \
+                if (oppFirst && fused0) bt_path_kernel<NDV, false, false, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
+                else if (oppFirst) bt_path_kernel<NDV, true, false, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);          \
                 else if (oppLast && sel) bt_path_kernel<NDV, false, true, ACC, false, true, true, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
                 else if (sel) bt_path_kernel<NDV, false, true, ACC, false, false, true, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);   \
                 else if (oppLast) bt_path_kernel<NDV, false, true, ACC, false, true, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);      \
                 else if (ndir == 1) bt_path_kernel<NDV, true, true, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);        \
-                else if (i == 0) bt_path_kernel<NDV, true, false, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
+                else if (i == 0 && !fused0) bt_path_kernel<NDV, true, false, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);     \
                 else if (i == ndir - 1) bt_path_kernel<NDV, false, true, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines); \
                 else bt_path_kernel<NDV, false, false, ACC, false, false, false, PKV><<<gp, 256, 0, s>>>(pa, dx, dy, nlines);                \
             } while (0)

@@ -544,7 +544,7 @@ enum {
     MDISP_TUNE_SGM_FORCE_PREPASS = 3,  /* 1: upright strips + diagonal pre-pass even when byte path states fit      */
     MDISP_TUNE_SGM_LANES16 = 4,        /* 1: sixteen lanes per pixel whatever the disparity count                   */
     MDISP_TUNE_SGM_PER_DIRECTION = 5,  /* 1: one kernel per path direction (the fallback of unsupported shapes)     */
-    MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other (what large problems do); 2: the same with the selection as a kernel of its own instead of inside the last direction */
+    MDISP_TUNE_SGBM_BT_SEQUENTIAL = 6, /* 1: StereoSGBM replacement runs its directions one launch after the other (what large problems do); 2: the same with the selection as a kernel of its own instead of inside the last direction; 3: the same as 1 with the vertical window sum and the downward path as two kernels */
     MDISP_TUNE_SGM_PIPELINE = 7,       /* batches: 0 = row bands with four paths per sweep (default), 1 = sheared strips with a separate horizontal scan */
     MDISP_TUNE_SGM_PLANT_ERROR = 8,    /* 1: the next pipelined SGM call finds its hand-off error word already set  */
     MDISP_TUNE_SGM_BAND_SLACK = 9,     /* row bands: pixels a band stays behind its predecessor beyond the minimum  */

@@ -48,14 +48,17 @@ CASES = [
 # running group sum kept in memory -- the tuning switch selects the second schedule at test sizes
 # -- the tuning switch selects the second schedule at test sizes, with the selection inside the last direction (as large
 # problems run it) or as a kernel of its own
-@pytest.fixture(params=["one launch per group", "one launch per direction", "one launch per direction, separate selection"])
+@pytest.fixture(params=["one launch per group", "one launch per direction", "one launch per direction, separate selection",
+                        "one launch per direction, separate vertical sum"])
 def bt_schedule(request):
     from cameracalibration_amd import _lib
     _lib.tuning_reset()
     if request.param == "one launch per direction":
         _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 1)
-    elif request.param != "one launch per group":
+    elif request.param == "one launch per direction, separate selection":
         _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 2)
+    elif request.param != "one launch per group":
+        _lib.tuning_set(_lib.TUNE_SGBM_BT_SEQUENTIAL, 3)
     yield request.param
     _lib.tuning_reset()
 
