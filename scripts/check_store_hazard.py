@@ -50,7 +50,11 @@ def regs(operand):
 
 
 def scan(co):
-    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    return scan_text(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout)
+
+
+def scan_text(txt):
+    """(offending pairs, number of wide buffer stores with a register scalar offset) of a disassembly listing."""
     found, stores, func = [], 0, "?"
     lines = [l for l in txt.split("\n")]
     prev = None

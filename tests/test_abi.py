@@ -83,9 +83,14 @@ def test_no_wide_buffer_store_is_followed_by_an_overwrite_of_its_data():
     if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
         import pytest
         pytest.skip("no llvm-objdump")
-    # the pattern itself, on a listing of the faulty form
-    import re
+    # the pattern itself, on listings of the faulty form and of the guarded one
     assert mod.regs("v[14:17]") == {14, 15, 16, 17} and mod.regs("v14") == {14}
+    faulty = "0000000000001000 <kernel>:\n\tbuffer_store_dwordx4 v[14:17], v55, s[52:55], s57 offen nt sc1\n\tv_max_i32_e32 v14, 0, v45\n"
+    guarded = faulty.replace("\tv_max", "\ts_nop 0\n\tv_max")
+    other = faulty.replace("v_max_i32_e32 v14", "v_max_i32_e32 v18")
+    immediate = faulty.replace(", s57 offen", ", 0 offen")         # the compiler covers this form itself
+    assert len(mod.scan_text(faulty)[0]) == 1 and mod.scan_text(faulty)[1] == 1
+    assert mod.scan_text(guarded) == ([], 1) and mod.scan_text(other) == ([], 1) and mod.scan_text(immediate) == ([], 0)
     import sys
     argv = sys.argv
     try:
