@@ -121,7 +121,14 @@ __global__ __launch_bounds__(256) void mc_minmax_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { lo = min(lo, (u32)__shfl_xor((int)lo, m, 64)); hi = max(hi, (u32)__shfl_xor((int)hi, m, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[2 * blockIdx.y], lo); atomicMax(&mm[2 * blockIdx.y + 1], hi); }
+    // one pair of atomics per workgroup: hundreds of slices x hundreds of waves on the same two words queue up otherwise
+    __shared__ u32 slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&mm[2 * blockIdx.y], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
+        atomicMax(&mm[2 * blockIdx.y + 1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
+    }
 }
 
 // per-column minimum / maximum of an interleaved 8-bit image over all rows and channels
@@ -461,7 +468,8 @@ int md_mc_filter_wta(hipStream_t s, const McGuideHost& gh, int H, int W, int r, 
         else P = dSlices + (size_t)k0 * N;
         mc_mm_init_kernel<<<(m + 63) / 64, 64, 0, s>>>(pmm, m);
         int mb = (int)((N + 256 * 8 - 1) / (256 * 8));
-        if (mb > 512) mb = 512;
+        const int mbMax = m >= 64 ? 16 : (m >= 8 ? 64 : 512);      // enough workgroups over all slices; few atomics per slice
+        if (mb > mbMax) mb = mbMax;
         mc_minmax_kernel<<<dim3(mb, m), 256, 0, s>>>(P, N, pmm);
         mc_coeff_kernel<<<m, 256, 0, s>>>(g, W, k0, aMin, aMax, bMin, bMax, pmm, gco, pco);
         float* const Vout = dFiltered ? dFiltered + (size_t)k0 * N : V;

@@ -21,8 +21,9 @@ for v in "--P2 300 --pairs 16" "--paths 5" "--tune SGM_PIPELINE=1"; do
   timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $v >> $O/bench_side.jsonl 2>> $O/bench.err
 done
 # --- the other paths: one target script per family, three runs each (kernel stats, fetched bytes, written bytes)
-for T in other_paths stereosgbm_1080p main_pipeline; do
+for T in other_paths stereosgbm_1080p main_pipeline guidedf; do
   case $T in
+    guidedf) CMD="scripts/prof_guidedf.py 1";;
     other_paths) CMD="scripts/other_paths_rate.py";;
     stereosgbm_1080p) CMD="scripts/prof_stereosgbm.py 1080p";;
     main_pipeline) CMD="scripts/main_pipeline_rate.py";;
