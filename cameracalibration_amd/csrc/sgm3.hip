@@ -142,6 +142,9 @@ __device__ __forceinline__ void sgm3_rows_body(const RowArgs& ra, const int band
 
     if (threadIdx.x >= NT) {
         if (HONLY) return;      // rows are independent: nothing to exchange
+#ifdef SGM3_COMM_PRIO
+        __builtin_amdgcn_s_setprio(SGM3_COMM_PRIO);
+#endif
         // ---- communication wave: publishes the last slot's states one step behind the compute waves and fetches
         // the states slot 0 will consume one step ahead of them
         const int lane = threadIdx.x - NT, which = lane / LPC, lic = lane % LPC;
@@ -880,7 +883,10 @@ __global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, S4B, S
 // winner-take-all.  A second-sweep band waits for the first-sweep band of the other direction that covers the same image
 // rows (an earlier ticket: it has started), so the GPU fills once and drains once per call instead of once per phase.
 template <bool TAIL, int LPC, int NRT, int NT>
-__global__ __launch_bounds__(NT + 64, sgm3_waves_per_simd(LPC, NRT, TAIL, true, false, 1)) void sgm3_meet_kernel(RowArgs ra)
+#ifndef SGM3_MEET_WPS
+#define SGM3_MEET_WPS sgm3_waves_per_simd(LPC, NRT, TAIL, true, false, 1)
+#endif
+__global__ __launch_bounds__(NT + 64, SGM3_MEET_WPS) void sgm3_meet_kernel(RowArgs ra)
 {
     constexpr int SLOTS = NT / LPC, DPLn = 2 * NRT, SW = sgm3_state_dwords(LPC, NRT, false);
     __shared__ u32 st[2][SLOTS + 1][3][SW];
