@@ -10,12 +10,28 @@ LIB = os.path.join(HERE, "lib", "libmdisp.so")
 SOURCES = ["api.hip", "census.hip", "sgm.hip", "sgm2.hip", "sgm3.hip", "sgbm_bt.hip", "bm.hip", "fgs.hip", "legacy.hip", "ncc.hip", "stereo.hip", "filters.hip", "gif_mc.hip", "host.hip", "multi.hip"]
 
 
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "mdisp.h")]
+
+
+def _obj(src):
+    return os.path.join(HERE, "lib", "obj", src.replace(".hip", ".o"))
+
+
+def _outdated(src):
+    """A source is recompiled when its object is missing or older than the source or any header."""
+    obj = _obj(src)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + _headers())
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mdisp.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(_outdated(s) or os.path.getmtime(_obj(s)) > t for s in SOURCES)
 
 
 def build(force=False, verbose=False):
@@ -23,29 +39,29 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
     procs = []
-    objdir = os.path.join(HERE, "lib", "obj")
-    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(HERE, "lib", "obj"), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if not force and not _outdated(src):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wall", "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             failed = True
+            if os.path.exists(_obj(src)):
+                os.remove(_obj(src))          # never link an object of an earlier version of a source that no longer compiles
             sys.stderr.write(f"--- {src} ---\n{out}\n")
         elif verbose and out.strip():
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES]
     subprocess.check_call(cmd)
     return LIB
 
