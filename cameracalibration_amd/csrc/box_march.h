@@ -61,6 +61,7 @@ __global__ __launch_bounds__(MW) void dual_box_march_kernel(MarchGeom g, Load ld
     const int x0 = blockIdx.x * MW, y0 = g.yA + blockIdx.y * g.band, y1 = min(g.yB, y0 + g.band), k = blockIdx.z;
     const int tx = threadIdx.x, x = x0 + tx, wave = tx >> 6, lane = tx & 63;
     ld.begin(k);
+    if (ld.skip(k)) return;      // (the same for the whole workgroup) nothing to do for this slice
     // the two row elements this thread loads: tx and tx + MW; source column and validity fixed per thread
     int xsrc[2]; bool xok[2];
 #pragma unroll
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(64) void dual_box_march_small_kernel(MarchGeom g, L
     const int x0 = blockIdx.x * MWF, y0 = g.yA + blockIdx.y * g.band, y1 = min(g.yB, y0 + g.band), k = blockIdx.z;
     const int lane = threadIdx.x, c0 = 2 * lane, x = x0 + c0;
     ld.begin(k);
+    if (ld.skip(k)) return;      // (the same for the whole workgroup) nothing to do for this slice
     // source columns of the (at most three) row elements this lane loads, reflected once
     constexpr int NLD = (ROWW + 63) / 64;
     int xsrc[NLD];

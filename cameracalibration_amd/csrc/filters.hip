@@ -384,6 +384,7 @@ struct LoadCostGP {
     CostSrc c; int k0; const u32* mm; int mode; const float* G;
     NormScale ns;
     struct Raw { int r, p; float g; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int k) { ns = norm_scale(mm[2 * k], mm[2 * k + 1]); }
     __device__ Raw fetch(int x, int y, int k) const
     {
@@ -404,6 +405,7 @@ struct LoadCostGP {
 struct LoadPlanarGP {
     const float* P; size_t N; int W; const float* G;
     struct Raw { float p, g; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int) {}
     __device__ Raw fetch(int x, int y, int k) const
     {
@@ -418,6 +420,7 @@ struct LoadPlanarGP {
 struct LoadAB {
     const float* A; const float* B; size_t N; int W; const float* w;
     struct Raw { float a, b, ww; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int) {}
     __device__ Raw fetch(int x, int y, int k) const
     {

@@ -292,9 +292,15 @@ __device__ __forceinline__ int mc_guide_raw(const McGuide& g, int c, int x, int 
 }
 __device__ __forceinline__ float mc_norm(int v, const float2& co) { return __fadd_rn(__fmul_rn((float)v, co.x), co.y); }
 
+// A channel of the view that does not move with the candidate (offset step 0) has the same mean and variance in every
+// slice whose guide normalisation equals the first slice's (the usual case: the guide's extremes are 0 and 255 everywhere):
+// those slices are skipped here and read the first slice's planes.
+__device__ __forceinline__ bool mc_same_as_first(const float2* gco, int k)
+{ return k > 0 && gco[k].x == gco[0].x && gco[k].y == gco[0].y; }
 struct McLoadGG {
-    McGuide g; int c, k0; const float2* gco; float2 gc;
+    McGuide g; int c, k0; const float2* gco; float2 gc; bool fixedView;
     struct Raw { int v; };
+    __device__ bool skip(int k) const { return fixedView && mc_same_as_first(gco, k); }
     __device__ void begin(int k) { gc = gco[k]; }
     __device__ Raw fetch(int x, int y, int k) const { Raw r; r.v = mc_guide_raw(g, c, x, y, k0 + k); return r; }
     __device__ void finish(const Raw& r, float& q0, float& q1) const { q0 = mc_norm(r.v, gc); q1 = __fmul_rn(q0, q0); }
@@ -311,6 +317,7 @@ struct McStoreMV {
 struct McLoadPGP {
     McGuide g; int c, k0; const float* P; size_t N; int W; const float2* gco; const float2* pco; float2 gc, pc;
     struct Raw { float p; int v; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int k) { gc = gco[k]; pc = pco[k]; }
     __device__ Raw fetch(int x, int y, int k) const { Raw r; r.p = P[(size_t)k * N + (size_t)y * W + x]; r.v = mc_guide_raw(g, c, x, y, k0 + k); return r; }
     __device__ void finish(const Raw& r, float& q0, float& q1) const
@@ -321,10 +328,12 @@ struct McLoadPGP {
 };
 struct McStoreA {
     float* A; float* DOT; float* B; const float* MG; const float* VAR; size_t N; int W, cn, c, variant; float epsf; double scale;
+    const float2* gco; bool fixedView;
     __device__ void operator()(int x, int y, int k, double s0, double s1) const
     {
         const size_t i = (size_t)y * W + x, o = (size_t)k * N + i;
-        const float mp = (float)(s0 * scale), cgp = (float)(s1 * scale), mg = MG[o], var = VAR[o];
+        const size_t om = fixedView && mc_same_as_first(gco, k) ? i : o;          // the first slice's planes (McLoadGG::skip)
+        const float mp = (float)(s0 * scale), cgp = (float)(s1 * scale), mg = MG[om], var = VAR[om];
         const float cov = __fsub_rn(cgp, __fmul_rn(mg, mp));
         float den;
         if (variant == 0) den = __fadd_rn(var, epsf);
@@ -340,6 +349,7 @@ struct McStoreA {
 struct McLoadPlanes {
     const float* P0; const float* P1; size_t kstride, N; int W;
     struct Raw { float a, b; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int) {}
     __device__ Raw fetch(int x, int y, int k) const
     {
@@ -368,6 +378,7 @@ struct McStoreDot {
 struct McLoadCost {
     McCost c; int k0;
     struct Raw { int a, b; };
+    __device__ bool skip(int) const { return false; }
     __device__ void begin(int) {}
     __device__ Raw fetch(int x, int y, int k) const
     {
@@ -484,11 +495,12 @@ int md_mc_filter_wta(hipStream_t s, const McGuideHost& gh, int H, int W, int r, 
             mc_out_kernel<<<grid, 256, lds, s>>>(oa);
         } else {
             for (int c = 0; c < cn; c++) {
-                McLoadGG lgg{g, c, k0, gco, {}};
+                const bool fixedView = c < g.acn ? g.aOffStep == 0 : g.bOffStep == 0;
+                McLoadGG lgg{g, c, k0, gco, {}, fixedView};
                 McStoreMV smv{MG, VAR, N, W, scale};
                 MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, lgg, smv));
                 McLoadPGP lp{g, c, k0, P, N, W, gco, pco, {}, {}};
-                McStoreA sa{A, DOT, Bp, MG, VAR, N, W, cn, c, variant, (float)eps, scale};
+                McStoreA sa{A, DOT, Bp, MG, VAR, N, W, cn, c, variant, (float)eps, scale, gco, fixedView};
                 MD_TRY(dual_box_march(s, m, H, W, r, 0, 0, H, lp, sa));
             }
             for (int c = 0; c < cn; c += 2) {
