@@ -21,6 +21,14 @@ typedef unsigned int u32;
 #define A3X(INS, SUF) asm volatile(INS " %0, %1, %2 " SUF : "=v"(a[i]) : "v"(a[i]), "v"(B))
 #define A2P(INS, SUF) asm volatile(INS " %0, %1 " SUF : "+v"(a[i]) : "v"(B))
 
+// eight instructions in the proportions of the first sweep's loop: 2 plain adds, 2 packed minima, 1 three-input minimum,
+// 1 permute, 1 population count, 1 cross-lane minimum (the figure printed is per instruction of the mix)
+#define MIXED                                                                                                              \
+    do {                                                                                                                   \
+        if (i == 0 || i == 4) A3("v_add_u32"); else if (i == 1 || i == 5) A3("v_pk_min_u16"); else if (i == 2) A4("v_pk_minimum3_f16"); \
+        else if (i == 3) A4("v_perm_b32"); else if (i == 6) A3("v_bcnt_u32_b32");                                          \
+        else A3X("v_min_u32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf");                                                \
+    } while (0)
 #define OPS(X)                                                                                                             \
     X(0, "v_add_u32", A3("v_add_u32"))                                                                                     \
     X(1, "v_pk_minimum3_f16", A4("v_pk_minimum3_f16"))                                                                     \
@@ -55,7 +63,9 @@ typedef unsigned int u32;
     X(30, "v_pk_add_u16", A3("v_pk_add_u16"))                                                                              \
     X(31, "v_exp_f32", A2("v_exp_f32"))                                                                                    \
     X(32, "v_fma_f32", A4("v_fma_f32"))                                                                                    \
-    X(33, "v_pk_fma_f32", asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p[i & 3]) : "v"(p[i & 3]), "v"(p[(i + 1) & 3]), "v"(p[(i + 2) & 3])))
+    X(33, "v_pk_fma_f32", asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p[i & 3]) : "v"(p[i & 3]), "v"(p[(i + 1) & 3]), "v"(p[(i + 2) & 3]))) \
+    X(34, "v_pk_min_u16_same_bank", asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[(i + 4) & 7])))                 \
+    X(35, "mixed_stream_of_the_sweep", MIXED)
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(u32* out, unsigned long long* clk, int iters, u32 seed)
