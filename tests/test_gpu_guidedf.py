@@ -123,6 +123,25 @@ def test_adaptive_weight_guidedf(api, orc, is_left, shape, eps, win, minD, numD)
         assert (inner == minD + numD // 2).mean() > 0.7                 # finds the synthetic shift
 
 
+@pytest.mark.parametrize("which", [1, 2, 3])
+def test_guided_filter_matchers_at_the_reference_size(api, which):
+    """1280 x 720 colour pair at the reference's own default arguments (methods/method_StereoMatching.h:179-187: window 35,
+    minDisparity 186, 144 candidates) -- too large for the oracle in a test, so a size-independent property: the views
+    differ by a constant shift inside the candidate range, and away from the border the matchers on a dissimilarity recover it.
+    (_3 takes the MINIMUM of the reference's correlation measure, as the reference does, so it does not find the shift: its
+    map only has to be finite and inside the candidate range.)"""
+    H, W, shift = 720, 1280, 250
+    L, R = _colour_pair(1234, H, W, shift)
+    sm = api.stereomatch_1
+    fn = {1: sm.computeAdaptiveWeight_GuidedF, 2: sm.computeAdaptiveWeight_GuidedF_2, 3: sm.computeAdaptiveWeight_GuidedF_3}[which]
+    got = fn(L, R)
+    assert got.dtype == np.float32 and got.shape == (H, W) and np.isfinite(got).all()
+    assert got.min() >= 0 and got.max() <= 186 + 143
+    inner = got[40:-40, 186 + 144 + 40:-40]
+    if which != 3:
+        assert (np.abs(inner - shift) <= 1).mean() > 0.9
+
+
 def test_stereo_matching_dispatches_the_guided_filter_entry(api, orc):
     """stereoMatching(ADAPTIVE_WEIGHT_GUIDED_FILTER) = computeAdaptiveWeight_GuidedF(L, R, DISPARITY_LEFT, 0.01, 15, 10, 150)
     (methods/methods.cpp:1801-1803)."""
