@@ -96,7 +96,8 @@ def test_stereosgbm_full_size_frame_bit_exact(api, orc, mode):
 @pytest.mark.parametrize("shape", [(48, 150, 1, (0, 64, 7, 490, 1960, 1, 63, 10, 100, 32, 0), 7, 0),
                                    (37, 140, 3, (2, 32, 5, 8 * 3 * 25, 32 * 3 * 25, 2, 31, 15, 50, 2, 1), 5, 2),
                                    (270, 960, 1, (0, 128, 7, 490, 1960, 1, 63, 10, 100, 32, 0), 6, 0),
-                                   (20, 50, 1, (0, 64, 5), 3, 1)])
+                                   (20, 50, 1, (0, 64, 5), 3, 1),
+                                   (1080, 1920, 1, (0, 256, 7, 490, 1960, 1, 63, 10, 100, 32, 0), 3, 0)])
 def test_stereosgbm_batch_equals_the_single_pair_call(api, orc, shape):
     """mdisp_stereosgbm_batch_dev: pairs side by side on the context's streams, every map equal to the single-pair entry point's
     (and the first one to the oracle), with work enqueued before and after the call on the context's stream; lanes = 0: default."""
